@@ -1,0 +1,1226 @@
+/*
+ * rt_oracle.cpp -- CPU restatement of the per-pixel render loop of
+ * Crhonopost/Ray-tracing (reference @ 2025-01-17).
+ *
+ * TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  PARITY UNPINNED: the reference
+ * path cannot be compiled in this image (needs <GL/glut.h>) and ships no tests.
+ *
+ * Every function cites the reference file:line it restates.  Arithmetic is
+ * IEEE float32 in the reference's operation order (build with
+ * -ffp-contract=off); places where the reference promotes to double are
+ * written as double here too.
+ */
+#include "rt_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+/* ---------------------------------------------------------------- Vec3.h */
+struct V3 {
+    float v[3];
+    V3() { v[0] = v[1] = v[2] = 0.f; }                       /* Vec3.h:16 */
+    explicit V3(float s) { v[0] = v[1] = v[2] = s; }         /* Vec3.h:17 */
+    V3(float x, float y, float z) { v[0] = x; v[1] = y; v[2] = z; }
+    float& operator[](int i) { return v[i]; }
+    float operator[](int i) const { return v[i]; }
+};
+inline V3 operator+(const V3& a, const V3& b) { return V3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); } /* Vec3.h:97 */
+inline V3 operator-(const V3& a, const V3& b) { return V3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); } /* Vec3.h:100 */
+inline V3 operator*(float a, const V3& b) { return V3(a * b[0], a * b[1], a * b[2]); }              /* Vec3.h:103 */
+inline V3 operator*(const V3& b, float a) { return V3(a * b[0], a * b[1], a * b[2]); }              /* Vec3.h:106 */
+inline V3 operator/(const V3& a, float b) { return V3(a[0] / b, a[1] / b, a[2] / b); }              /* Vec3.h:109 */
+inline float dot(const V3& a, const V3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }      /* Vec3.h:38 */
+inline V3 cross(const V3& a, const V3& b) {                                                          /* Vec3.h:41 */
+    return V3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+}
+inline float sqlen(const V3& a) { return a[0] * a[0] + a[1] * a[1] + a[2] * a[2]; }                 /* Vec3.h:29 */
+/* Vec3.h:32: unqualified sqrt(float) resolves to ::sqrt(double), result narrowed to float. */
+inline float len(const V3& a) { return (float)std::sqrt((double)sqlen(a)); }
+inline void normalize(V3& a) { float L = len(a); a[0] /= L; a[1] /= L; a[2] /= L; }                 /* Vec3.h:37 */
+inline V3 comp(const V3& a, const V3& b) { return V3(a[0] * b[0], a[1] * b[1], a[2] * b[2]); }      /* Vec3.h:66 */
+
+struct M3 { float m[9]; };                                                                           /* Vec3.h:121 */
+inline V3 mul(const M3& a, const V3& p) {                                                            /* Vec3.h:156 */
+    return V3(a.m[0] * p[0] + a.m[1] * p[1] + a.m[2] * p[2],
+              a.m[3] * p[0] + a.m[4] * p[1] + a.m[5] * p[2],
+              a.m[6] * p[0] + a.m[7] * p[1] + a.m[8] * p[2]);
+}
+
+/* Line.h:13-16: a Ray normalises its direction on construction. */
+struct Ray {
+    V3 o, d;
+    Ray() {}
+    Ray(const V3& o_, const V3& d_) : o(o_), d(d_) { normalize(d); }
+};
+
+struct Box {                                                                                         /* AccelerationStruct.h:26-32 */
+    V3 mn, mx;
+    Box() : mn(INFINITY), mx(-INFINITY) {}
+    Box(const V3& a, const V3& b) : mn(a), mx(b) {}
+    V3 center() const { return (mn + mx) / 2.f; }                                                    /* AccelerationStruct.cpp:32-34 */
+};
+
+enum { MAT_DIFFUSE = 0, MAT_GLASS = 1, MAT_MIRROR = 2, MAT_CHECKER = 3 };                           /* Material.h:10-15 */
+
+struct Mat {                                                                                         /* Material.h:18-47 */
+    V3 ka, kd, ks;
+    double shininess = 0.0;     /* uninitialised in the reference; defined as 0.0 (hard parts) */
+    int type = MAT_DIFFUSE;
+    float ior = 1.0f, transparency = 0.0f, reflectivity = 0.0f;
+};
+
+struct Node {
+    bool leaf = true;
+    int64_t l = -1, r = -1;
+    Box box;
+    std::vector<int64_t> items; /* trianglesIdx or object ordinals */
+};
+struct Tree {
+    std::vector<Node> nodes;    /* nodes[0] = root, DFS pre-order */
+};
+
+struct MeshObj {
+    std::vector<V3> pos, nrm;
+    std::vector<uint32_t> tri;  /* 3 per triangle */
+    Mat mat;
+    Tree tree;
+    int64_t ntri() const { return (int64_t)tri.size() / 3; }
+};
+struct SquareObj { V3 vtx[4]; Mat mat; };
+struct SphereObj { V3 c; float r = 0; Mat mat; };
+struct Light { V3 pos; float radius = 0; V3 color; };
+
+struct Stats {
+    uint64_t prim = 0, sec = 0, shad = 0, box = 0, tri = 0, node = 0, sbox = 0, stri = 0, snode = 0;
+    void add(const Stats& o) {
+        prim += o.prim; sec += o.sec; shad += o.shad; box += o.box; tri += o.tri; node += o.node;
+        sbox += o.sbox; stri += o.stri; snode += o.snode;
+    }
+};
+thread_local Stats tl_stats;
+
+struct HitRec {                                                                                      /* Ray.h:13-24 */
+    bool exists = false;
+    float t = FLT_MAX;
+    V3 pos, nrm;
+    double u = 0, v = 0;
+    const Mat* mat = nullptr;
+    int obj = -1, tri = 0;
+};
+
+std::string g_asset_dir = "assets/models";
+
+}  // namespace
+
+struct orc_scene {
+    std::vector<MeshObj> meshes;
+    std::vector<SphereObj> spheres;
+    std::vector<SquareObj> squares;
+    std::vector<Light> lights;
+    Tree top;
+    int n_obj() const { return (int)(squares.size() + spheres.size() + meshes.size()); }
+};
+
+namespace {
+
+/* ------------------------------------------------------------ counter RNG
+ * Replaces glibc random()/rand() (Scene.h:115-116, main.cpp:195-196); keyed by
+ * path identity so the order of evaluation does not matter (north_star). */
+inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+inline uint32_t rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code, uint32_t light, uint32_t i, uint32_t which) {
+    uint32_t h = mix32(seed + 0x9e3779b9U);
+    h = mix32((h ^ pixel) + 0x9e3779b9U);
+    h = mix32((h ^ sample) + 0x9e3779b9U);
+    h = mix32((h ^ (uint32_t)code) + 0x9e3779b9U);
+    h = mix32((h ^ (uint32_t)(code >> 32)) + 0x9e3779b9U);
+    h = mix32((h ^ light) + 0x9e3779b9U);
+    h = mix32((h ^ i) + 0x9e3779b9U);
+    h = mix32((h ^ which) + 0x9e3779b9U);
+    return h;
+}
+
+/* ------------------------------------------------------ AABB::intersect
+ * AccelerationStruct.cpp:13-30. std::max(a,b) = (a<b)?b:a, std::min(a,b) = (b<a)?b:a. */
+inline bool slab(const Ray& ray, const Box& box, float& tEnter, bool shadow) {
+    tl_stats.box++;
+    if (shadow) tl_stats.sbox++;
+    float tMin = 0.0f, tMax = 100.0f;
+    for (int i = 0; i < 3; i++) {
+        float invD = 1.0f / ray.d[i];
+        float t0 = (box.mn[i] - ray.o[i]) * invD;
+        float t1 = (box.mx[i] - ray.o[i]) * invD;
+        if (invD < 0.0f) std::swap(t0, t1);
+        tMin = (tMin < t0) ? t0 : tMin;
+        tMax = (t1 < tMax) ? t1 : tMax;
+        if (tMin > tMax) { tEnter = -1.0f; return false; }
+    }
+    tEnter = tMin;
+    return true;
+}
+
+/* ------------------------------------------------- Triangle (Triangle.h) */
+struct TriHit { bool exists; float t, w0, w1, w2; V3 p, n; };
+
+inline TriHit tri_intersect(const V3& c0, const V3& c1, const V3& c2, const Ray& ray, bool shadow) {
+    tl_stats.tri++;
+    if (shadow) tl_stats.stri++;
+    TriHit r;
+    r.exists = false;
+    /* Triangle.h:28-33 updateAreaAndNormal */
+    V3 nn = cross(c1 - c0, c2 - c0);
+    float norm = len(nn);
+    V3 n = nn / norm;
+    float area = norm / 2.f;
+    /* Triangle.h:49-53 isParallelTo */
+    if (dot(ray.d, n) == 0) return r;
+    /* Triangle.h:54-64 getIntersectionPointWithSupportPlane */
+    float D = dot(c0, n);
+    float t = (D - dot(ray.o, n)) / dot(ray.d, n);
+    V3 P = ray.o + t * ray.d;
+    /* Triangle.h:94-96 */
+    V3 cd = P - ray.o;
+    normalize(cd);
+    if (dot(cd, ray.d) < 0) return r;
+    /* Triangle.h:65-84 computeBarycentricCoordinates: (C.length() / 2.) / area in double -> float */
+    float u0, u1, u2;
+    {
+        V3 toP = P - c1, side = c2 - c1;
+        V3 C = cross(side, toP);
+        u0 = (float)(((double)len(C) / 2.) / (double)area);
+        toP = P - c2; side = c0 - c2;
+        C = cross(side, toP);
+        u1 = (float)(((double)len(C) / 2.) / (double)area);
+        toP = P - c0; side = c1 - c0;
+        C = cross(side, toP);
+        u2 = (float)(((double)len(C) / 2.) / (double)area);
+    }
+    float sum = u0 + u1 + u2;
+    if ((double)sum < 0.9999 || (double)sum > 1.00001) return r;   /* Triangle.h:105 */
+    r.exists = true;
+    r.t = len(ray.o - P);                                           /* Triangle.h:110 */
+    r.p = P; r.n = n; r.w0 = u0; r.w1 = u1; r.w2 = u2;
+    return r;
+}
+
+/* -------------------------------------- BVH_Node::intersect (per mesh)
+ * AccelerationStruct.cpp:255-283: all triangles of all leaves whose box chain is
+ * hit, near child first (tL <= tR). Appending in visit order equals the
+ * reference's vector concatenation. */
+void mesh_candidates(const Tree& tr, int64_t ni, const Ray& ray, std::vector<int64_t>& out, bool shadow) {
+    const Node& nd = tr.nodes[ni];
+    if (nd.leaf) {
+        out.insert(out.end(), nd.items.begin(), nd.items.end());
+        return;
+    }
+    tl_stats.node++;
+    if (shadow) tl_stats.snode++;
+    float tL, tR;
+    bool hitL = slab(ray, tr.nodes[nd.l].box, tL, shadow);
+    bool hitR = slab(ray, tr.nodes[nd.r].box, tR, shadow);
+    if (hitL && !hitR) mesh_candidates(tr, nd.l, ray, out, shadow);
+    else if (hitR && !hitL) mesh_candidates(tr, nd.r, ray, out, shadow);
+    else if (hitL && hitR) {
+        if (tL <= tR) { mesh_candidates(tr, nd.l, ray, out, shadow); mesh_candidates(tr, nd.r, ray, out, shadow); }
+        else { mesh_candidates(tr, nd.r, ray, out, shadow); mesh_candidates(tr, nd.l, ray, out, shadow); }
+    }
+}
+
+/* RayTraceMesh::intersect, Mesh.cpp:97-138 */
+HitRec mesh_intersect(const MeshObj& m, const Ray& ray, bool shadow) {
+    thread_local std::vector<int64_t> cand;
+    cand.clear();
+    mesh_candidates(m.tree, 0, ray, cand, shadow);
+    bool exists = false;
+    float bestT = FLT_MAX;
+    V3 bestN;
+    float bw0 = 0, bw1 = 0;
+    int64_t bestTri = 0;
+    for (int64_t ti : cand) {
+        const uint32_t* iv = &m.tri[3 * ti];
+        V3 p0 = m.pos[iv[0]] * 1.0001f;       /* Mesh.cpp:107-109: Vec3 * double literal -> operator*(Vec3,float) */
+        V3 p1 = m.pos[iv[1]] * 1.0001f;
+        V3 p2 = m.pos[iv[2]] * 1.0001f;
+        TriHit h = tri_intersect(p0, p1, p2, ray, shadow);
+        if (h.exists && h.t < bestT) {
+            exists = true;
+            bestT = h.t;
+            bestN = m.nrm[iv[0]] * h.w0 + m.nrm[iv[1]] * h.w1 + m.nrm[iv[2]] * h.w2;   /* Mesh.cpp:121 */
+            bw0 = h.w0; bw1 = h.w1;
+            bestTri = ti;
+        }
+    }
+    HitRec r;
+    r.exists = exists;
+    r.t = bestT;
+    if (exists) {
+        r.nrm = bestN;
+        normalize(r.nrm);                      /* Mesh.cpp:130 */
+        r.pos = ray.o + ray.d * bestT;         /* Mesh.cpp:131 */
+        r.u = bw0; r.v = bw1;
+        r.tri = (int)bestTri;
+    }
+    r.mat = &m.mat;
+    return r;
+}
+
+/* Sphere::intersect, Sphere.h:86-146 (u,v omitted: only image textures read them). */
+HitRec sphere_intersect(const SphereObj& s, const Ray& ray) {
+    HitRec miss;
+    V3 dir = ray.d;
+    V3 oMinC = ray.o - s.c;
+    float a = dot(dir, dir);
+    float b = 2 * dot(oMinC, dir);
+    float c = dot(oMinC, oMinC) - (s.r * s.r);
+    float disc = (b * b) - (4.f * a * c);
+    float t = 0;
+    if (disc > 0) {
+        float sq = (float)std::sqrt((double)disc);
+        float t1 = (-b - sq) / (2 * a);
+        float t2 = (-b + sq) / (2 * a);
+        if (t1 > 0 && t2 > 0) t = (t2 < t1) ? t2 : t1;   /* std::min(t1,t2) */
+        else if (t1 > 0) t = t1;
+        else if (t2 > 0) t = t2;
+        else return miss;
+    } else if (disc == 0) {
+        t = (float)((double)(-b) / (2. * (double)a));      /* Sphere.h:113 */
+    }
+    HitRec r;
+    if (t != 0.) {
+        V3 P = ray.o + dir * t;
+        V3 n = P - s.c;
+        normalize(n);
+        if (dot(ray.d, n) > 0.) return miss;               /* Sphere.h:122 back-face cull */
+        r.exists = true;
+        r.t = t;
+        r.nrm = n;
+        r.pos = ray.o + ray.d * t;
+    }
+    r.mat = &s.mat;
+    return r;
+}
+
+/* Square::intersect, Square.h:62-111 */
+HitRec square_intersect(const SquareObj& q, const Ray& ray) {
+    HitRec miss;
+    V3 bl = q.vtx[0];
+    V3 right = q.vtx[1] - q.vtx[0];
+    V3 up = q.vtx[3] - q.vtx[0];
+    V3 n = cross(right, up);
+    normalize(n);
+    if (dot(ray.d, n) > 0) return miss;
+    float D = dot(bl, n);
+    float t = (D - dot(ray.o, n)) / dot(ray.d, n);
+    HitRec r;
+    if (t > 0 && !std::isinf(t)) {
+        V3 P = ray.o + t * ray.d;
+        V3 d = P - bl;
+        float u = dot(d, right) / sqlen(right);
+        float v = dot(d, up) / sqlen(up);
+        if (u >= 0 && u <= 1.0 && v >= 0 && v <= 1.0) {
+            r.exists = true;
+            r.t = t;
+            r.nrm = n;
+            r.pos = ray.o + ray.d * t;
+            r.u = u; r.v = v;
+        }
+    }
+    r.mat = &q.mat;
+    return r;
+}
+
+HitRec object_intersect(const orc_scene& sc, int64_t ord, const Ray& ray, bool shadow) {
+    int nsq = (int)sc.squares.size(), nsp = (int)sc.spheres.size();
+    HitRec h;
+    if (ord < nsq) h = square_intersect(sc.squares[ord], ray);
+    else if (ord < nsq + nsp) h = sphere_intersect(sc.spheres[ord - nsq], ray);
+    else h = mesh_intersect(sc.meshes[ord - nsq - nsp], ray, shadow);
+    h.obj = (int)ord;
+    return h;
+}
+
+/* BVH_Node::intersectObjects, AccelerationStruct.cpp:286-337 */
+HitRec top_intersect(const orc_scene& sc, int64_t ni, const Ray& ray, float lightDistance, bool stopAtFirst) {
+    const Node& nd = sc.top.nodes[ni];
+    if (nd.leaf) {
+        HitRec result;
+        for (int64_t ord : nd.items) {
+            HitRec h = object_intersect(sc, ord, ray, stopAtFirst);
+            if (h.exists && h.t < result.t) {
+                result = h;
+                if (stopAtFirst && h.t <= lightDistance) return result;
+            }
+        }
+        return result;
+    }
+    tl_stats.node++;
+    if (stopAtFirst) tl_stats.snode++;
+    float tL, tR;
+    bool hitL = slab(ray, sc.top.nodes[nd.l].box, tL, stopAtFirst);
+    bool hitR = slab(ray, sc.top.nodes[nd.r].box, tR, stopAtFirst);
+    if (hitL && !hitR) return top_intersect(sc, nd.l, ray, lightDistance, stopAtFirst);
+    if (hitR && !hitL) return top_intersect(sc, nd.r, ray, lightDistance, stopAtFirst);
+    if (hitL && hitR) {
+        HitRec L = top_intersect(sc, nd.l, ray, lightDistance, stopAtFirst);
+        if (stopAtFirst && L.exists) return L;
+        HitRec R = top_intersect(sc, nd.r, ray, lightDistance, stopAtFirst);
+        if (stopAtFirst && R.exists) return R;
+        return L.t <= R.t ? L : R;
+    }
+    return HitRec();
+}
+
+/* Scene::isInShadow, Scene.h:160-168 */
+bool in_shadow(const orc_scene& sc, const V3& P, const V3& L) {
+    V3 dir = L - P;
+    float length = len(dir);
+    normalize(dir);
+    Ray ray(P + dir * 0.001f, dir);
+    tl_stats.shad++;
+    HitRec r = top_intersect(sc, 0, ray, length, true);
+    return r.exists && r.t <= length;
+}
+
+struct TraceCtx {
+    const orc_scene* sc;
+    const orc_params* prm;
+    uint32_t pixel, sample;
+};
+
+/* Scene::sampleSphereLight, Scene.h:110-134 with random() -> counter RNG. */
+float sample_sphere_light(const TraceCtx& c, uint64_t code, uint32_t li, const V3& P, const Light& light) {
+    int S = c.prm->light_samples;
+    if (c.prm->shadow_mode == 1)                        /* Scene.h:215, the hard-shadow variant */
+        return in_shadow(*c.sc, P, light.pos) ? 1.f : 0.f;
+    float shadowCount = 0.f;
+    float degToRad = (float)(M_PI / 180.);
+    for (int i = 0; i < S; i++) {
+        float randY = (float)(long)(rng(c.prm->seed, c.pixel, c.sample, code, li, (uint32_t)i, 0) % 360u) * degToRad;
+        float randX = (float)(long)(rng(c.prm->seed, c.pixel, c.sample, code, li, (uint32_t)i, 1) % 360u) * degToRad;
+        V3 position(0.f, (float)(-std::sin((double)randY)), (float)std::cos((double)randY));
+        position[0] = (float)(-std::sin((double)randX) * (double)position[2]);
+        position[2] = (float)(std::cos((double)randX) * (double)position[2]);
+        position = position * light.radius;             /* position *= radius */
+        V3 areaLightPos = light.pos + position;
+        if (in_shadow(*c.sc, P, areaLightPos)) shadowCount += 1.f;
+    }
+    return shadowCount / (float)S;
+}
+
+/* Scene::phong, Scene.h:90-108 */
+V3 phong(const V3& Li, const V3& lightPos, const V3& P, const V3& N, const V3& V, const V3& ka, const V3& kd, const V3& ks, double shininess) {
+    V3 Ld = lightPos - P;
+    normalize(Ld);
+    float theta = dot(N, Ld);
+    V3 ambient = comp(Li, ka);
+    V3 diffuse = comp(Li, kd) * ((theta < 0.f) ? 0.f : theta);              /* std::max(theta, 0.f) */
+    V3 r = (float)(2. * (double)theta) * N - Ld;
+    float rv = dot(r, V);
+    float rDotV = (0.0f < rv) ? rv : 0.0f;                                  /* std::max(0.0f, r.V) */
+    V3 specular = comp(Li, ks) * (float)std::pow((double)rDotV, shininess);
+    return ambient + diffuse + specular;
+}
+
+/* Material::reflect, Material.h:60-65 (non-standard on purpose) */
+V3 reflect_dir(const V3& d, const V3& n) {
+    V3 md = -1.f * d;
+    V3 parallel = dot(md, n) * n - md;
+    V3 out = n + parallel;
+    normalize(out);
+    return out;
+}
+/* Material::refract, Material.h:67-76 */
+V3 refract_dir(const V3& d, const V3& n, float ri, float cosTheta) {
+    V3 perp = ri * (d + cosTheta * n);
+    float k = (float)(1.0 - (double)sqlen(perp));
+    if (k < 0.0) return V3(0.f, 0.f, 0.f);
+    V3 para = -std::sqrt(k) * n;
+    V3 out = para + perp;
+    normalize(out);
+    return out;
+}
+/* Material::reflectance, Material.h:79-84 */
+double schlick(double cosine, double ri) {
+    double r0 = (1 - ri) / (1 + ri);
+    r0 = r0 * r0;
+    return r0 + (1 - r0) * std::pow((1 - cosine), 5);
+}
+
+/* Scene::rayTraceRecursive, Scene.h:174-280 */
+V3 trace(const TraceCtx& c, const Ray& ray, int remaining, uint64_t code, HitRec* firstHit) {
+    if (code == 1) tl_stats.prim++; else tl_stats.sec++;
+    HitRec h = top_intersect(*c.sc, 0, ray, 0.f, false);
+    if (firstHit) *firstHit = h;
+    V3 color(0.1f, 0.2f, 0.3f);
+    if (!h.exists) {                                                          /* Scene.h:274-278 */
+        float t = (float)(0.5 * ((double)ray.d[1] + 1.0));
+        float omt = (float)(1.0 - (double)t);
+        return omt * V3(1.0f) + t * V3(0.5f, 0.7f, 1.0f);
+    }
+    const V3 P = h.pos, N = h.nrm;
+    Mat m = *h.mat;
+    if (m.type == MAT_CHECKER) {                                              /* Material.h:153-161, Scene.h:51,192-197 */
+        float inv = (float)(1. / 3.f);
+        int xi = (int)std::floor(inv * P[0]), yi = (int)std::floor(inv * P[1]), zi = (int)std::floor(inv * P[2]);
+        bool even = (xi + yi + zi) % 2 == 0;
+        V3 col = even ? V3(0.f) : V3(1.f);
+        m.kd = col; m.ks = col;
+    }
+    if (m.type == MAT_DIFFUSE || m.type == MAT_CHECKER || remaining <= 0) {  /* Scene.h:204-222 */
+        color = V3(0.f);
+        float avg = 0.f;
+        const auto& lights = c.sc->lights;
+        for (size_t li = 0; li < lights.size(); li++) {
+            avg += sample_sphere_light(c, code, (uint32_t)li, P, lights[li]);
+            V3 ph = phong(lights[li].color, lights[li].pos, P, N, -1.f * ray.d, m.ka, m.kd, m.ks, m.shininess);
+            color = color + ph;
+        }
+        float f = (float)(1. - (double)(avg / (float)lights.size()));
+        return color * f;
+    }
+    if (m.type == MAT_MIRROR) {                                               /* Scene.h:225-229 */
+        V3 nd = reflect_dir(ray.d, N);
+        Ray nr(P + N * 0.001f, nd);
+        V3 child = trace(c, nr, remaining - 1, code * 2, nullptr);
+        return comp(m.ks, child) * m.reflectivity;
+    }
+    /* glass, Scene.h:230-272 */
+    float cosTheta = (float)std::fmin((double)dot(-1.f * ray.d, N), 1.);
+    float sinTheta = (float)std::sqrt(1.0 - (double)(cosTheta * cosTheta));
+    bool inside = cosTheta < 0.;
+    float ri = inside ? m.ior : (float)(1. / (double)m.ior);
+    double R = schlick((double)cosTheta, (double)ri);
+    V3 rd = reflect_dir(ray.d, N);
+    Ray reflRay(P + N * 0.001f, rd);
+    V3 reflC = trace(c, reflRay, remaining - 1, code * 2, nullptr);
+    V3 refrC(0.f);
+    if (!((double)(ri * sinTheta) > 1.0)) {
+        double off = inside ? 0.00001 : -0.00001;
+        V3 fd = refract_dir(ray.d, N, ri, cosTheta);
+        if (sqlen(fd) != 0) {
+            Ray refrRay(P + ((float)off * N), fd);
+            refrC = trace(c, refrRay, remaining - 1, code * 2 + 1, nullptr);
+        }
+    }
+    color = (float)R * reflC + (float)(1.0 - R) * refrC;
+    color = (float)(1.0 - (double)m.transparency) * color + m.transparency * refrC;
+    V3 absorb = (V3(1.f) - m.kd) * -(h.t * m.transparency);
+    for (int i = 0; i < 3; i++) absorb[i] = std::exp(absorb[i]);             /* std::exp(float) */
+    return comp(color, absorb);
+}
+
+/* ----------------------------------------------------------- BVH builders */
+struct BTri { int64_t index; V3 avg; Box box; };                             /* AccelerationStruct.h:77-85 */
+struct BObj { Box box; int64_t ord; };                                       /* AccelerationStruct.h:88-96 */
+
+/* BVH_Node ctor for triangles, AccelerationStruct.cpp:151-195. The reference copies
+ * the two halves into new vectors; partitioning the sub-range in place yields the
+ * same element order. */
+int64_t build_tri_node(Tree& tr, std::vector<BTri>& bt, int64_t lo, int64_t hi, int depth, const Box& box) {
+    int64_t me = (int64_t)tr.nodes.size();
+    tr.nodes.emplace_back();
+    tr.nodes[me].box = box;
+    int64_t n = hi - lo;
+    if (depth > 0 && n > 1) {
+        tr.nodes[me].leaf = false;
+        V3 diag = box.mx - box.mn;
+        int axis = diag[0] > std::max(diag[1], diag[2]) ? 0 : diag[1] > diag[2] ? 1 : 2;
+        V3 center = box.mn + diag / 2.f;
+        auto mid = std::partition(bt.begin() + lo, bt.begin() + hi,
+                                  [center, axis](const BTri& b) { return b.avg[axis] < center[axis]; });
+        int64_t m = mid - bt.begin();
+        auto range_box = [&](int64_t a, int64_t b) {                         /* AccelerationStruct.cpp:57-69 */
+            Box g = bt[a].box;
+            for (int64_t i = a; i < b; i++)
+                for (int k = 0; k < 3; k++) {
+                    g.mn[k] = std::min(g.mn[k], bt[i].box.mn[k]);
+                    g.mx[k] = std::max(g.mx[k], bt[i].box.mx[k]);
+                }
+            return g;
+        };
+        int64_t l, r;
+        if (m - lo >= 1) l = build_tri_node(tr, bt, lo, m, depth - 1, range_box(lo, m));
+        else l = build_tri_node(tr, bt, lo, lo, 0, Box());
+        if (hi - m >= 1) r = build_tri_node(tr, bt, m, hi, depth - 1, range_box(m, hi));
+        else r = build_tri_node(tr, bt, m, m, 0, Box());
+        tr.nodes[me].l = l; tr.nodes[me].r = r;
+    } else {
+        for (int64_t i = lo; i < hi; i++) tr.nodes[me].items.push_back(bt[i].index);
+    }
+    return me;
+}
+
+/* BVH_Node::buildBVH(positions, triangles, ...), AccelerationStruct.cpp:91-113 + 36-55 */
+void build_mesh_tree(MeshObj& m, int depth) {
+    std::vector<BTri> bt((size_t)m.ntri());
+    for (int64_t i = 0; i < m.ntri(); i++) {
+        V3 a = m.pos[m.tri[3 * i]], b = m.pos[m.tri[3 * i + 1]], c = m.pos[m.tri[3 * i + 2]];
+        bt[i].index = i;
+        bt[i].avg = (a + b + c) / 3.f;
+        V3 mn = a, mx = a;
+        const V3 vs[2] = {b, c};
+        for (const V3& p : vs)
+            for (int k = 0; k < 3; k++) { mn[k] = std::min(p[k], mn[k]); mx[k] = std::max(p[k], mx[k]); }
+        bt[i].box = Box(mn, mx);
+    }
+    Box box;
+    for (const V3& p : m.pos)
+        for (int k = 0; k < 3; k++) {
+            box.mn[k] = p[k] < box.mn[k] ? p[k] : box.mn[k];
+            box.mx[k] = p[k] > box.mx[k] ? p[k] : box.mx[k];
+        }
+    m.tree.nodes.clear();
+    build_tri_node(m.tree, bt, 0, (int64_t)bt.size(), depth, box);
+}
+
+/* BVH_Node ctor for objects, AccelerationStruct.cpp:197-243 (axis counter shared by reference). */
+int64_t build_obj_node(Tree& tr, std::vector<BObj>& bo, int64_t lo, int64_t hi, int depth, const Box& box, int& axisCounter) {
+    int64_t me = (int64_t)tr.nodes.size();
+    tr.nodes.emplace_back();
+    tr.nodes[me].box = box;
+    int64_t n = hi - lo;
+    if (depth > 0 && n > 2) {
+        tr.nodes[me].leaf = false;
+        V3 diag = box.mx - box.mn;
+        axisCounter %= 3;
+        int axis = axisCounter;
+        V3 center = box.mn + diag / 2.f;
+        auto mid = std::partition(bo.begin() + lo, bo.begin() + hi,
+                                  [center, axis](const BObj& b) { return b.box.center()[axis] < center[axis]; });
+        int64_t m = mid - bo.begin();
+        axisCounter++;
+        auto range_box = [&](int64_t a, int64_t b) {                         /* AccelerationStruct.cpp:77-89 */
+            Box g = bo[a].box;
+            for (int64_t i = a; i < b; i++)
+                for (int k = 0; k < 3; k++) {
+                    g.mn[k] = std::min(g.mn[k], bo[i].box.mn[k]);
+                    g.mx[k] = std::max(g.mx[k], bo[i].box.mx[k]);
+                }
+            return g;
+        };
+        int64_t l, r;
+        if (m - lo >= 1) l = build_obj_node(tr, bo, lo, m, depth - 1, range_box(lo, m), axisCounter);
+        else l = build_obj_node(tr, bo, lo, lo, 0, Box(), axisCounter);
+        if (hi - m >= 1) r = build_obj_node(tr, bo, m, hi, depth - 1, range_box(m, hi), axisCounter);
+        else r = build_obj_node(tr, bo, m, m, 0, Box(), axisCounter);
+        tr.nodes[me].l = l; tr.nodes[me].r = r;
+    } else {
+        for (int64_t i = lo; i < hi; i++) tr.nodes[me].items.push_back(bo[i].ord);
+    }
+    return me;
+}
+
+Box square_box(const SquareObj& q) {                                         /* Square.h:113-123 */
+    V3 mn = q.vtx[0], mx = q.vtx[0];
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], q.vtx[j][k]); mx[k] = std::max(mx[k], q.vtx[j][k]); }
+    return Box(mn, mx);
+}
+Box sphere_box(const SphereObj& s) { V3 d(s.r); return Box(s.c - d, s.c + d); }  /* Sphere.h:148-151 */
+
+/* BVH_Node::buildBVH(squares, spheres, meshes, deepLimit), AccelerationStruct.cpp:115-148 */
+void build_top_tree(orc_scene& sc, int depth) {
+    std::vector<BObj> bo;
+    int64_t ord = 0;
+    for (auto& q : sc.squares) bo.push_back({square_box(q), ord++});
+    for (auto& s : sc.spheres) bo.push_back({sphere_box(s), ord++});
+    for (auto& m : sc.meshes) bo.push_back({m.tree.nodes[0].box, ord++});   /* Mesh.cpp:181-183 */
+    Box box;
+    for (auto& b : bo)
+        for (int k = 0; k < 3; k++) { box.mn[k] = std::min(box.mn[k], b.box.mn[k]); box.mx[k] = std::max(box.mx[k], b.box.mx[k]); }
+    sc.top.nodes.clear();
+    int axisCounter = 0;
+    build_obj_node(sc.top, bo, 0, (int64_t)bo.size(), depth, box, axisCounter);
+}
+
+/* ------------------------------------------------------ Mesh host helpers */
+void recompute_normals(MeshObj& m) {                                         /* Mesh.cpp:25-38 */
+    m.nrm.assign(m.pos.size(), V3(0.f, 0.f, 0.f));
+    for (int64_t i = 0; i < m.ntri(); i++) {
+        uint32_t a = m.tri[3 * i], b = m.tri[3 * i + 1], c = m.tri[3 * i + 2];
+        V3 e01 = m.pos[b] - m.pos[a];
+        V3 e02 = m.pos[c] - m.pos[a];
+        V3 n = cross(e01, e02);
+        normalize(n);
+        m.nrm[a] = m.nrm[a] + n; m.nrm[b] = m.nrm[b] + n; m.nrm[c] = m.nrm[c] + n;
+    }
+    for (auto& n : m.nrm) normalize(n);
+}
+template <class T> void translate(T& pts, size_t n, const V3& t) { for (size_t i = 0; i < n; i++) pts[i] = pts[i] + t; }  /* Mesh.h:128-132 */
+template <class T> void apply_matrix(T& pts, size_t n, const M3& mt) { for (size_t i = 0; i < n; i++) pts[i] = mul(mt, pts[i]); }  /* Mesh.h:134-137 */
+M3 scale_matrix(const V3& s) { return M3{{s[0], 0.f, 0.f, 0.f, s[1], 0.f, 0.f, 0.f, s[2]}}; }       /* Mesh.h:144-149 */
+M3 rot_x(float angle) {                                                                               /* Mesh.h:151-157 */
+    float a = (float)((double)angle * M_PI / 180.);
+    float c = (float)std::cos((double)a), s = (float)std::sin((double)a);
+    return M3{{1.f, 0.f, 0.f, 0.f, c, -s, 0.f, s, c}};
+}
+M3 rot_y(float angle) {                                                                               /* Mesh.h:159-165 */
+    float a = (float)((double)angle * M_PI / 180.);
+    float c = (float)std::cos((double)a), s = (float)std::sin((double)a);
+    return M3{{c, 0.f, s, 0.f, 1.f, 0.f, -s, 0.f, c}};
+}
+void center_and_scale_to_unit(MeshObj& m) {                                                           /* Mesh.cpp:40-53 */
+    V3 c(0.f, 0.f, 0.f);
+    for (auto& p : m.pos) c = c + p;
+    c = c / (float)m.pos.size();
+    float maxD = len(m.pos[0] - c);
+    for (auto& p : m.pos) { float d = len(p - c); if (d > maxD) maxD = d; }
+    for (auto& p : m.pos) p = (p - c) / maxD;
+}
+
+bool load_off(const std::string& path, std::vector<V3>& pos, std::vector<uint32_t>& tri) {            /* Mesh.cpp:5-23 */
+    std::ifstream in(path.c_str());
+    if (!in) return false;
+    std::string offString;
+    unsigned int sizeV, sizeT, tmp;
+    in >> offString >> sizeV >> sizeT >> tmp;
+    pos.resize(sizeV);
+    tri.resize(3 * (size_t)sizeT);
+    for (unsigned int i = 0; i < sizeV; i++) in >> pos[i][0] >> pos[i][1] >> pos[i][2];
+    int s;
+    for (unsigned int i = 0; i < sizeT; i++) {
+        in >> s;
+        for (unsigned int j = 0; j < 3; j++) in >> tri[3 * i + j];
+    }
+    return true;
+}
+
+/* Square::setQuad, Square.h:31-60 */
+SquareObj make_quad(const V3& bottomLeft, const V3& rightVector, const V3& upVector, float width, float height) {
+    SquareObj q;
+    V3 r = rightVector, u = upVector;
+    normalize(r); normalize(u);
+    r = r * width; u = u * height;
+    q.vtx[0] = bottomLeft;
+    q.vtx[1] = bottomLeft + r;
+    q.vtx[2] = bottomLeft + r + u;
+    q.vtx[3] = bottomLeft + u;
+    return q;
+}
+struct QuadPts { SquareObj& q; V3& operator[](size_t i) { return q.vtx[i]; } };
+
+float frand01() { return (float)rand() / (float)RAND_MAX; }   /* (float) rand() / RAND_MAX */
+
+Light make_light(const V3& p, float radius) { Light l; l.pos = p; l.radius = radius; l.color = V3(1.f, 1.f, 1.f); return l; }
+
+SquareObj big_floor(float sx, float sy) {
+    /* setQuad(-1,-1,0; 1,0,0; 0,1,0; 2,2) ; translate(0,0,-2) ; scale(sx,sy,1) ; rotate_x(-90) -- e.g. Scene.h:847-850 */
+    SquareObj s = make_quad(V3(-1.f, -1.f, 0.f), V3(1.f, 0.f, 0.f), V3(0.f, 1.f, 0.f), 2.f, 2.f);
+    QuadPts p{s};
+    translate(p, 4, V3(0.f, 0.f, -2.f));
+    apply_matrix(p, 4, scale_matrix(V3(sx, sy, 1.f)));
+    apply_matrix(p, 4, rot_x(-90.f));
+    return s;
+}
+
+bool add_off_mesh(orc_scene& sc, const char* file, MeshObj& m) {
+    (void)sc;
+    return load_off(g_asset_dir + "/" + file, m.pos, m.tri);
+}
+
+/* Scene::setup_refraction_scene, Scene.h:468-552 */
+int setup_refraction(orc_scene& sc) {
+    sc.lights.push_back(make_light(V3(0.0f, 3.5f, 0.0f), .5f));
+    SquareObj s = big_floor(80.f, 80.f);
+    s.mat.kd = V3(0.75f, 1.f, 0.75f); s.mat.ks = V3(0.75f, 1.f, 0.75f); s.mat.shininess = 16; s.mat.type = MAT_CHECKER;
+    sc.squares.push_back(s);
+    SphereObj g; g.c = V3(0.f, 0.f, 0.5f); g.r = 0.75f;
+    g.mat.type = MAT_GLASS; g.mat.kd = V3(1.f, 0.f, 0.f); g.mat.ks = V3(1.f, 0.f, 0.f); g.mat.shininess = 16;
+    g.mat.transparency = 0.1f; g.mat.ior = 1.4f;
+    sc.spheres.push_back(g);
+    return 0;
+}
+/* Scene::setup_reflexion_scene, Scene.h:554-599 */
+int setup_reflexion(orc_scene& sc) {
+    sc.lights.push_back(make_light(V3(0.0f, 3.5f, 0.0f), .5f));
+    SquareObj s = big_floor(80.f, 80.f);
+    s.mat.kd = V3(0.75f, 1.f, 0.75f); s.mat.ks = V3(0.75f, 1.f, 0.75f); s.mat.shininess = 16; s.mat.type = MAT_CHECKER;
+    sc.squares.push_back(s);
+    SphereObj g; g.c = V3(0.f, -1.25f, 0.5f); g.r = 0.75f;
+    g.mat.type = MAT_MIRROR; g.mat.kd = V3(0.75f, 1.f, 1.f); g.mat.ks = V3(0.75f, 1.f, 1.f); g.mat.shininess = 16;
+    g.mat.transparency = 1.0f; g.mat.ior = 1.4f; g.mat.reflectivity = 0.5f;
+    sc.spheres.push_back(g);
+    return 0;
+}
+/* Floor + back wall + light of Scene::setup_test_scene, Scene.h:722-756 */
+void test_scene_room(orc_scene& sc) {
+    sc.lights.push_back(make_light(V3(1.0f, 2.5f, 0.0f), .5f));
+    SquareObj f = big_floor(2.f, 2.f);
+    f.mat.kd = V3(1.f, 1.f, 1.f); f.mat.ks = V3(1.f, 1.f, 1.f); f.mat.shininess = 16;
+    sc.squares.push_back(f);
+    SquareObj w = make_quad(V3(-1.f, -1.f, 0.f), V3(1.f, 0.f, 0.f), V3(0.f, 1.f, 0.f), 2.f, 2.f);
+    QuadPts p{w};
+    apply_matrix(p, 4, scale_matrix(V3(2.f, 2.f, 1.f)));
+    translate(p, 4, V3(0.f, 0.f, -2.f));
+    w.mat.kd = V3(0.5f, 0.f, 0.5f); w.mat.ks = V3(0.5f, 0.f, 0.5f); w.mat.shininess = 16;
+    sc.squares.push_back(w);
+}
+/* The commented-out gorilla block of setup_test_scene, Scene.h:768-781 (BASELINE config 4). */
+int setup_mesh_scene(orc_scene& sc, const char* file, bool unit) {
+    test_scene_room(sc);
+    sc.meshes.emplace_back();
+    MeshObj& m = sc.meshes.back();
+    if (!add_off_mesh(sc, file, m)) return -2;
+    if (unit) center_and_scale_to_unit(m);
+    else apply_matrix(m.pos, m.pos.size(), scale_matrix(V3(0.0125f)));
+    translate(m.pos, m.pos.size(), V3(0.f, -1.05f, 0.f));
+    recompute_normals(m);
+    m.mat.kd = V3(1.f, 1.f, 1.f); m.mat.ks = V3(1.f, 1.f, 1.f); m.mat.shininess = 16;
+    return 0;
+}
+
+/* Scene::setup_final_scene, Scene.h:800-970. Consumes glibc rand() from seed 1
+ * exactly as main() does when this scene is set up first (main.cpp:387-393). */
+int setup_final(orc_scene& sc) {
+    srand(1);
+    const V3 nice[10][2] = {
+        {V3(1.0f, 0.0f, 0.0f), V3(0.5f, 0.0f, 0.0f)}, {V3(0.0f, 1.0f, 0.0f), V3(0.0f, 0.5f, 0.0f)},
+        {V3(0.0f, 0.0f, 1.0f), V3(0.0f, 0.0f, 0.5f)}, {V3(1.0f, 1.0f, 0.0f), V3(0.5f, 0.5f, 0.0f)},
+        {V3(1.0f, 0.5f, 0.0f), V3(0.5f, 0.25f, 0.0f)}, {V3(0.5f, 0.0f, 1.0f), V3(0.25f, 0.0f, 0.5f)},
+        {V3(0.0f, 1.0f, 1.0f), V3(0.0f, 0.5f, 0.5f)}, {V3(1.0f, 0.0f, 1.0f), V3(0.5f, 0.0f, 0.5f)},
+        {V3(0.5f, 0.5f, 0.5f), V3(0.25f, 0.25f, 0.25f)}, {V3(1.0f, 1.0f, 1.0f), V3(0.5f, 0.5f, 0.5f)}};
+    sc.lights.push_back(make_light(V3(4.0f, 0.f, 10.f), .5f));
+    sc.lights.push_back(make_light(V3(-6.f, 2.f, 1.25f), 10.75f));
+    {
+        SquareObj s = big_floor(20.f, 20.f);
+        s.mat.kd = V3(1.f); s.mat.ks = V3(1.f); s.mat.shininess = 16; s.mat.type = MAT_CHECKER;
+        sc.squares.push_back(s);
+    }
+    {
+        sc.meshes.emplace_back();
+        MeshObj& m = sc.meshes.back();
+        if (!add_off_mesh(sc, "gorilla18_fixed.obj.off", m)) return -2;
+        apply_matrix(m.pos, m.pos.size(), scale_matrix(V3(0.04f)));
+        translate(m.pos, m.pos.size(), V3(-5.f, -1.9f, 0.f));
+        recompute_normals(m);
+        m.mat.type = MAT_GLASS; m.mat.kd = V3(1.f, 0.f, 0.f); m.mat.ks = V3(1.f, 0.f, 0.f); m.mat.shininess = 16;
+        m.mat.transparency = 1.0f; m.mat.ior = 1.4f;
+    }
+    {
+        SphereObj s; s.c = V3(-4.f, 0.f, 7.f); s.r = 1.75f;
+        s.mat.kd = nice[0][0]; s.mat.ks = nice[0][1];
+        s.mat.type = MAT_GLASS; s.mat.transparency = 0.8f; s.mat.ior = 1.3f;
+        sc.spheres.push_back(s);
+    }
+    {
+        SphereObj s; s.c = V3(0.f); s.r = 3.75f;
+        s.mat.type = MAT_MIRROR; s.mat.kd = V3(1.f, 1.f, 1.f); s.mat.ks = V3(1.f, 1.f, 1.f); s.mat.reflectivity = 0.9f;
+        sc.spheres.push_back(s);
+    }
+    std::vector<V3> fpos; std::vector<uint32_t> ftri;
+    if (!load_off(g_asset_dir + "/flamingo.off", fpos, ftri)) return -2;
+    for (int i = 0; i < 30; i++) {
+        sc.meshes.emplace_back();
+        MeshObj& m = sc.meshes.back();
+        m.pos = fpos; m.tri = ftri;
+        float randZ = (float)((double)frand01() * 50. - 25.);
+        apply_matrix(m.pos, m.pos.size(), scale_matrix(V3(0.0125f)));
+        translate(m.pos, m.pos.size(), V3(0.f, -2.f, randZ));
+        apply_matrix(m.pos, m.pos.size(), rot_y((float)((double)frand01() * 360.)));
+        recompute_normals(m);
+        m.mat.kd = V3(1.f, 0.753f, 0.796f); m.mat.ks = V3(1.f, 0.753f, 0.796f); m.mat.shininess = 16;
+    }
+    for (int i = 0; i < 50; i++) {
+        SphereObj s;
+        s.r = (float)((double)frand01() + 0.5);
+        float randZ = (float)((double)frand01() * 50. - 25.);
+        float randX = (float)((double)frand01() * 50. - 25.);
+        float randY = (float)((double)frand01() * 20. - 2.);
+        s.c = V3(randX, randY, randZ);
+        (void)rand(); (void)rand(); (void)rand();                  /* unused randColor, Scene.h:947 */
+        int ci = rand() % 10;
+        s.mat.kd = nice[ci][0]; s.mat.ks = nice[ci][1];
+        s.mat.shininess = rand() % 16;
+        int randType = rand() % 3;
+        switch (randType) {
+            case 0:
+                s.mat.type = MAT_GLASS;
+                s.mat.transparency = (float)(rand() / RAND_MAX);   /* integer division, Scene.h:959 */
+                break;
+            case 1:
+                s.mat.type = MAT_MIRROR;
+                s.mat.reflectivity = (float)(rand() / RAND_MAX * 0.5 + 0.5);
+                s.mat.transparency = (float)(rand() / RAND_MAX * 0.5 + 0.5);
+                break;
+        }
+        sc.spheres.push_back(s);
+    }
+    return 0;
+}
+
+/* BASELINE config 5: synthetic triangle soup + floor + one light. */
+inline float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+int setup_soup(orc_scene& sc, int64_t ntri) {
+    sc.lights.push_back(make_light(V3(0.f, 8.f, 0.f), .5f));
+    SquareObj f = big_floor(2.f, 2.f);
+    f.mat.kd = V3(1.f, 1.f, 1.f); f.mat.ks = V3(1.f, 1.f, 1.f); f.mat.shininess = 16;
+    sc.squares.push_back(f);
+    sc.meshes.emplace_back();
+    MeshObj& m = sc.meshes.back();
+    m.pos.resize((size_t)ntri * 3);
+    m.tri.resize((size_t)ntri * 3);
+    for (int64_t k = 0; k < ntri; k++) {
+        float r[9];
+        for (uint32_t j = 0; j < 9; j++) r[j] = u01(rng(1u, (uint32_t)k, (uint32_t)(k >> 32), 0, 0xFFFFFFFEu, j, 0));
+        V3 c(-8.f + 16.f * r[0], -2.f + 8.f * r[1], -8.f + 16.f * r[2]);
+        V3 e1(-0.02f + 0.04f * r[3], -0.02f + 0.04f * r[4], -0.02f + 0.04f * r[5]);
+        V3 e2(-0.02f + 0.04f * r[6], -0.02f + 0.04f * r[7], -0.02f + 0.04f * r[8]);
+        m.pos[3 * k] = c; m.pos[3 * k + 1] = c + e1; m.pos[3 * k + 2] = c + e2;
+        m.tri[3 * k] = (uint32_t)(3 * k); m.tri[3 * k + 1] = (uint32_t)(3 * k + 1); m.tri[3 * k + 2] = (uint32_t)(3 * k + 2);
+    }
+    recompute_normals(m);
+    m.mat.kd = V3(0.8f, 0.8f, 0.8f); m.mat.ks = V3(0.8f, 0.8f, 0.8f); m.mat.shininess = 16;
+    return 0;
+}
+
+/* -------------------------------------------------------------- camera */
+struct CamMats { double pinv[16], mvinv[16]; V3 eye; };
+
+void mat4_mul(const double* a, const double* b, double* o) {   /* column-major a*b */
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += a[k * 4 + r] * b[c * 4 + k];
+            o[c * 4 + r] = s;
+        }
+}
+bool mat4_inv(const double* m, double* inv) {                  /* Gauss-Jordan, partial pivoting */
+    double a[4][8];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) { a[r][c] = m[c * 4 + r]; a[r][c + 4] = (r == c) ? 1.0 : 0.0; }
+    for (int i = 0; i < 4; i++) {
+        int p = i;
+        for (int r = i + 1; r < 4; r++) if (std::fabs(a[r][i]) > std::fabs(a[p][i])) p = r;
+        if (a[p][i] == 0.0) return false;
+        if (p != i) for (int c = 0; c < 8; c++) std::swap(a[p][c], a[i][c]);
+        double d = a[i][i];
+        for (int c = 0; c < 8; c++) a[i][c] /= d;
+        for (int r = 0; r < 4; r++) if (r != i) { double f = a[r][i]; for (int c = 0; c < 8; c++) a[r][c] -= f * a[i][c]; }
+    }
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) inv[c * 4 + r] = a[r][c + 4];
+    return true;
+}
+void rotmatrix(const float q[4], float m[16]) {               /* Trackball.cpp:323-345 */
+    m[0] = (float)(1.0 - 2.0 * (double)(q[1] * q[1] + q[2] * q[2]));
+    m[1] = (float)(2.0 * (double)(q[0] * q[1] - q[2] * q[3]));
+    m[2] = (float)(2.0 * (double)(q[2] * q[0] + q[1] * q[3]));
+    m[3] = 0.0f;
+    m[4] = (float)(2.0 * (double)(q[0] * q[1] + q[2] * q[3]));
+    m[5] = (float)(1.0 - 2.0 * (double)(q[2] * q[2] + q[0] * q[0]));
+    m[6] = (float)(2.0 * (double)(q[1] * q[2] - q[0] * q[3]));
+    m[7] = 0.0f;
+    m[8] = (float)(2.0 * (double)(q[2] * q[0] - q[1] * q[3]));
+    m[9] = (float)(2.0 * (double)(q[1] * q[2] + q[0] * q[3]));
+    m[10] = (float)(1.0 - 2.0 * (double)(q[1] * q[1] + q[0] * q[0]));
+    m[11] = 0.0f;
+    m[12] = m[13] = m[14] = 0.0f;
+    m[15] = 1.0f;
+}
+/* column-major mult of matrixUtilities.h:164-170 */
+inline void mult_cm(const double* m, double x, double y, double z, double w, double* r) {
+    r[0] = m[0] * x + m[4] * y + m[8] * z + m[12] * w;
+    r[1] = m[1] * x + m[5] * y + m[9] * z + m[13] * w;
+    r[2] = m[2] * x + m[6] * y + m[10] * z + m[14] * w;
+    r[3] = m[3] * x + m[7] * y + m[11] * z + m[15] * w;
+}
+/* Camera::apply (Camera.cpp:125-132), Camera::resize/gluPerspective (Camera.cpp:41-50),
+ * cameraSpaceToWorldSpace(0,0,0) (matrixUtilities.h:188-197). The GL driver's own
+ * matrix arithmetic is not reproducible; this is its closed form in double. */
+void camera_matrices(const orc_camera& cam, CamMats& cm) {
+    auto trans = [](double x, double y, double z, double* t) {
+        for (int i = 0; i < 16; i++) t[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        t[12] = x; t[13] = y; t[14] = z;
+    };
+    double t1[16], t2[16], rm[16], a[16], mv[16];
+    trans(cam.x, cam.y, cam.z, t1);
+    trans(0.0, 0.0, -(double)cam.zoom, t2);
+    float rf[16];
+    rotmatrix(cam.quat, rf);
+    for (int i = 0; i < 16; i++) rm[i] = rf[i];                /* glMultMatrixf reads m[4][4] as column-major */
+    mat4_mul(t1, t2, a);
+    mat4_mul(a, rm, mv);
+    double f = 1.0 / std::tan((double)cam.fovy_deg * M_PI / 360.0);
+    double zn = cam.znear, zf = cam.zfar;
+    double p[16] = {0};
+    p[0] = f / (double)cam.aspect; p[5] = f; p[10] = (zf + zn) / (zn - zf); p[11] = -1.0; p[14] = 2.0 * zf * zn / (zn - zf);
+    mat4_inv(p, cm.pinv);
+    mat4_inv(mv, cm.mvinv);
+    double r[4];
+    mult_cm(cm.mvinv, 0.0, 0.0, 0.0, 1.0, r);
+    cm.eye = V3((float)(r[0] / r[3]), (float)(r[1] / r[3]), (float)(r[2] / r[3]));
+}
+/* main.cpp:195-197 + matrixUtilities.h:198-222 */
+void primary_ray(const CamMats& cm, const orc_params& prm, int x, int y, int s, V3& pos, V3& dir) {
+    float ju = 0.5f, jv = 0.5f;
+    uint32_t pixel = (uint32_t)(x + y * prm.img_w);
+    if (prm.jitter) {
+        ju = (float)(rng(prm.seed, pixel, (uint32_t)s, 0, 0xFFFFFFFFu, 0, 0) & 0x7fffffffu) / (float)RAND_MAX;
+        jv = (float)(rng(prm.seed, pixel, (uint32_t)s, 0, 0xFFFFFFFFu, 0, 1) & 0x7fffffffu) / (float)RAND_MAX;
+    }
+    float u = ((float)x + ju) / (float)prm.img_w;
+    float v = ((float)y + jv) / (float)prm.img_h;
+    double ri[4], r[4];
+    mult_cm(cm.pinv, 2.0 * (double)u - 1.0, -(2.0 * (double)v - 1.0), 0.0, 1.0, ri);
+    mult_cm(cm.mvinv, ri[0], ri[1], ri[2], ri[3], r);
+    V3 p((float)(r[0] / r[3]), (float)(r[1] / r[3]), (float)(r[2] / r[3]));
+    pos = cm.eye;
+    dir = p - pos;
+    normalize(dir);
+}
+
+void fill_mat(const Mat& m, orc_material* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    for (int k = 0; k < 3; k++) { o->ka[k] = m.ka[k]; o->kd[k] = m.kd[k]; o->ks[k] = m.ks[k]; }
+    o->shininess = m.shininess; o->type = m.type; o->ior = m.ior; o->transparency = m.transparency; o->reflectivity = m.reflectivity;
+}
+Mat from_mat(const orc_material* o) {
+    Mat m;
+    if (!o) return m;
+    m.ka = V3(o->ka[0], o->ka[1], o->ka[2]); m.kd = V3(o->kd[0], o->kd[1], o->kd[2]); m.ks = V3(o->ks[0], o->ks[1], o->ks[2]);
+    m.shininess = o->shininess; m.type = o->type; m.ior = o->ior; m.transparency = o->transparency; m.reflectivity = o->reflectivity;
+    return m;
+}
+
+void export_stats(const Stats& s, orc_stats* o) {
+    if (!o) return;
+    o->rays_primary = s.prim; o->rays_secondary = s.sec; o->rays_shadow = s.shad;
+    o->box_tests = s.box; o->tri_tests = s.tri; o->node_visits = s.node;
+    o->sh_box_tests = s.sbox; o->sh_tri_tests = s.stri; o->sh_node_visits = s.snode;
+}
+
+}  // namespace
+
+/* ===================================================================== C API */
+extern "C" {
+
+orc_scene* orc_scene_new(void) { return new orc_scene(); }
+void orc_scene_free(orc_scene* s) { delete s; }
+void orc_set_asset_dir(const char* dir) { g_asset_dir = dir; }
+
+int orc_load_off(const char* path, float* verts, int max_v, uint32_t* tris, int max_t, int* nv, int* nt) {
+    std::vector<V3> pos; std::vector<uint32_t> tri;
+    if (!load_off(path, pos, tri)) return -2;
+    if (nv) *nv = (int)pos.size();
+    if (nt) *nt = (int)(tri.size() / 3);
+    if (verts) for (int i = 0; i < (int)pos.size() && i < max_v; i++) for (int k = 0; k < 3; k++) verts[3 * i + k] = pos[i][k];
+    if (tris) for (int i = 0; i < (int)(tri.size() / 3) && i < max_t; i++) for (int k = 0; k < 3; k++) tris[3 * i + k] = tri[3 * i + k];
+    return 0;
+}
+
+int orc_scene_setup(orc_scene* sc, const char* name) {
+    sc->meshes.clear(); sc->spheres.clear(); sc->squares.clear(); sc->lights.clear(); sc->top.nodes.clear();
+    std::string n(name);
+    if (n == "final") return setup_final(*sc);
+    if (n == "refraction") return setup_refraction(*sc);
+    if (n == "reflexion") return setup_reflexion(*sc);
+    if (n == "mesh_gorilla") return setup_mesh_scene(*sc, "gorilla18_fixed.obj.off", false);
+    if (n == "mesh_cow") return setup_mesh_scene(*sc, "cow.off", true);
+    if (n.rfind("soup:", 0) == 0) return setup_soup(*sc, atoll(n.c_str() + 5));
+    return -1;
+}
+
+int orc_add_light(orc_scene* sc, const float pos[3], float radius, const float color[3]) {
+    Light l; l.pos = V3(pos[0], pos[1], pos[2]); l.radius = radius; l.color = V3(color[0], color[1], color[2]);
+    sc->lights.push_back(l);
+    return 0;
+}
+int orc_add_square(orc_scene* sc, const float verts[12], const orc_material* m) {
+    SquareObj q;
+    for (int j = 0; j < 4; j++) q.vtx[j] = V3(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]);
+    q.mat = from_mat(m);
+    sc->squares.push_back(q);
+    return 0;
+}
+int orc_add_sphere(orc_scene* sc, const float c[3], float radius, const orc_material* m) {
+    SphereObj s; s.c = V3(c[0], c[1], c[2]); s.r = radius; s.mat = from_mat(m);
+    sc->spheres.push_back(s);
+    return 0;
+}
+int orc_add_mesh(orc_scene* sc, const float* verts, int nv, const uint32_t* tris, int nt, const orc_material* mt) {
+    sc->meshes.emplace_back();
+    MeshObj& m = sc->meshes.back();
+    m.pos.resize(nv);
+    for (int i = 0; i < nv; i++) m.pos[i] = V3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    m.tri.assign(tris, tris + 3 * (size_t)nt);
+    recompute_normals(m);
+    m.mat = from_mat(mt);
+    return 0;
+}
+
+int orc_build(orc_scene* sc, int top_depth, int mesh_depth) {
+    for (auto& m : sc->meshes) build_mesh_tree(m, mesh_depth);
+    build_top_tree(*sc, top_depth);
+    return 0;
+}
+
+int orc_counts(const orc_scene* sc, int* nsq, int* nsp, int* nm, int* nl) {
+    if (nsq) *nsq = (int)sc->squares.size();
+    if (nsp) *nsp = (int)sc->spheres.size();
+    if (nm) *nm = (int)sc->meshes.size();
+    if (nl) *nl = (int)sc->lights.size();
+    return 0;
+}
+int orc_get_square(const orc_scene* sc, int i, float verts[12], orc_material* m) {
+    if (i < 0 || i >= (int)sc->squares.size()) return -1;
+    for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) verts[3 * j + k] = sc->squares[i].vtx[j][k];
+    fill_mat(sc->squares[i].mat, m);
+    return 0;
+}
+int orc_get_sphere(const orc_scene* sc, int i, float c[3], float* radius, orc_material* m) {
+    if (i < 0 || i >= (int)sc->spheres.size()) return -1;
+    for (int k = 0; k < 3; k++) c[k] = sc->spheres[i].c[k];
+    *radius = sc->spheres[i].r;
+    fill_mat(sc->spheres[i].mat, m);
+    return 0;
+}
+int orc_get_light(const orc_scene* sc, int i, float pos[3], float* radius, float color[3]) {
+    if (i < 0 || i >= (int)sc->lights.size()) return -1;
+    for (int k = 0; k < 3; k++) { pos[k] = sc->lights[i].pos[k]; color[k] = sc->lights[i].color[k]; }
+    *radius = sc->lights[i].radius;
+    return 0;
+}
+int orc_get_mesh_counts(const orc_scene* sc, int i, int64_t* nv, int64_t* nt) {
+    if (i < 0 || i >= (int)sc->meshes.size()) return -1;
+    *nv = (int64_t)sc->meshes[i].pos.size(); *nt = sc->meshes[i].ntri();
+    return 0;
+}
+int orc_get_mesh(const orc_scene* sc, int i, float* verts, float* normals, uint32_t* tris, orc_material* m) {
+    if (i < 0 || i >= (int)sc->meshes.size()) return -1;
+    const MeshObj& ms = sc->meshes[i];
+    for (size_t j = 0; j < ms.pos.size(); j++)
+        for (int k = 0; k < 3; k++) {
+            if (verts) verts[3 * j + k] = ms.pos[j][k];
+            if (normals) normals[3 * j + k] = ms.nrm[j][k];
+        }
+    if (tris) memcpy(tris, ms.tri.data(), ms.tri.size() * sizeof(uint32_t));
+    fill_mat(ms.mat, m);
+    return 0;
+}
+
+int64_t orc_dump_tree(const orc_scene* sc, int which, int32_t* leaf, int32_t* count, float* boxes,
+                      int64_t max_nodes, int64_t* items, int64_t max_items, int64_t* n_items) {
+    const Tree* tr = nullptr;
+    if (which < 0) tr = &sc->top;
+    else if (which < (int)sc->meshes.size()) tr = &sc->meshes[which].tree;
+    else return -1;
+    int64_t ni = 0;
+    for (size_t i = 0; i < tr->nodes.size(); i++) {   /* nodes are stored in DFS pre-order */
+        const Node& n = tr->nodes[i];
+        if ((int64_t)i < max_nodes) {
+            if (leaf) leaf[i] = n.leaf ? 1 : 0;
+            if (count) count[i] = (int32_t)n.items.size();
+            if (boxes) for (int k = 0; k < 3; k++) { boxes[6 * i + k] = n.box.mn[k]; boxes[6 * i + 3 + k] = n.box.mx[k]; }
+        }
+        for (int64_t it : n.items) { if (items && ni < max_items) items[ni] = it; ni++; }
+    }
+    if (n_items) *n_items = ni;
+    return (int64_t)tr->nodes.size();
+}
+
+void orc_intersect(const orc_scene* sc, const float* org, const float* dir, int64_t n, orc_hit* out) {
+    for (int64_t i = 0; i < n; i++) {
+        Ray ray(V3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), V3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+        HitRec h = top_intersect(*sc, 0, ray, 0.f, false);
+        orc_hit& o = out[i];
+        memset(&o, 0, sizeof(o));
+        o.exists = h.exists ? 1 : 0;
+        o.obj = h.exists ? h.obj : -1;
+        o.tri = h.exists ? h.tri : 0;
+        o.t = h.exists ? h.t : FLT_MAX;
+        if (h.exists) {
+            for (int k = 0; k < 3; k++) { o.pos[k] = h.pos[k]; o.nrm[k] = h.nrm[k]; }
+            o.u = (float)h.u; o.v = (float)h.v;
+        }
+    }
+}
+void orc_shadow(const orc_scene* sc, const float* pts, const float* lp, int64_t n, int32_t* occluded) {
+    for (int64_t i = 0; i < n; i++)
+        occluded[i] = in_shadow(*sc, V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), V3(lp[3 * i], lp[3 * i + 1], lp[3 * i + 2])) ? 1 : 0;
+}
+void orc_trace(const orc_scene* sc, const float* org, const float* dir, int64_t n, const orc_params* prm,
+               const uint32_t* pixel, const uint32_t* sample, float* rgb) {
+    for (int64_t i = 0; i < n; i++) {
+        TraceCtx c{sc, prm, pixel ? pixel[i] : (uint32_t)i, sample ? sample[i] : 0u};
+        Ray ray(V3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), V3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+        V3 col = trace(c, ray, prm->max_depth, 1, nullptr);
+        for (int k = 0; k < 3; k++) rgb[3 * i + k] = col[k];
+    }
+}
+void orc_camera_rays(const orc_camera* cam, const orc_params* prm, int x0, int y0, int w, int h, float* org, float* dir) {
+    CamMats cm;
+    camera_matrices(*cam, cm);
+    int64_t k = 0;
+    for (int y = y0; y < y0 + h; y++)
+        for (int x = x0; x < x0 + w; x++)
+            for (int s = 0; s < prm->spp; s++, k++) {
+                V3 p, d;
+                primary_ray(cm, *prm, x, y, s, p, d);
+                for (int j = 0; j < 3; j++) { org[3 * k + j] = p[j]; dir[3 * k + j] = d[j]; }
+            }
+}
+
+double orc_render(const orc_scene* sc, const orc_camera* cam, const orc_params* prm, int x0, int y0, int w, int h,
+                  float* rgb, int32_t* prim, orc_stats* stats, int n_threads) {
+    CamMats cm;
+    camera_matrices(*cam, cm);
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<int64_t> next(0);
+    int64_t npix = (int64_t)w * h;
+    std::vector<Stats> st((size_t)n_threads);
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int tid) {
+        tl_stats = Stats();
+        for (;;) {                                           /* one task per pixel, main.cpp:210-225 */
+            int64_t p = next.fetch_add(1);
+            if (p >= npix) break;
+            int x = x0 + (int)(p % w), y = y0 + (int)(p / w);
+            V3 acc(0.f, 0.f, 0.f);
+            for (int s = 0; s < prm->spp; s++) {
+                V3 o, d;
+                primary_ray(cm, *prm, x, y, s, o, d);
+                TraceCtx c{sc, prm, (uint32_t)(x + y * prm->img_w), (uint32_t)s};
+                HitRec fh;
+                V3 col = trace(c, Ray(o, d), prm->max_depth, 1, s == 0 ? &fh : nullptr);
+                acc = acc + col;                             /* pixel_color += color */
+                if (s == 0 && prim) { prim[2 * p] = fh.exists ? fh.obj : -1; prim[2 * p + 1] = fh.exists ? fh.tri : 0; }
+            }
+            acc = acc / (float)prm->spp;                     /* pixel_color /= nsamples */
+            for (int k = 0; k < 3; k++) rgb[3 * p + k] = acc[k];
+        }
+        st[tid] = tl_stats;
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_threads; i++) th.emplace_back(worker, i);
+    worker(0);
+    for (auto& t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    Stats tot;
+    for (auto& s : st) tot.add(s);
+    export_stats(tot, stats);
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+void orc_quantize(const float* rgb, int64_t n, int32_t* out) {   /* main.cpp:253 */
+    for (int64_t i = 0; i < n; i++) out[i] = (int)(255.f * std::min<float>(1.f, rgb[i]));
+}
+void orc_rotmatrix(const float q[4], float m[16]) { rotmatrix(q, m); }
+uint32_t orc_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code, uint32_t light, uint32_t i, uint32_t which) {
+    return rng(seed, pixel, sample, code, light, i, which);
+}
+
+}  // extern "C"
