@@ -1,0 +1,188 @@
+/*
+ * rtgpu.h -- C-ABI of the MI355X render-loop library (librtgpu.so).
+ *
+ * Drop-in boundary for the ThreadPool CPU path of Crhonopost/Ray-tracing:
+ * the body of ray_trace_from_camera() (main.cpp:180-258: ray generation,
+ * per-pixel ThreadPool tasks, Scene::rayTrace, averaging) is replaced by
+ *     rt_upload_scene -> rt_set_camera -> rt_begin_frame -> rt_render_tile* ->
+ *     rt_download_framebuffer.
+ * The reference has no FFI of its own; each entry point cites the
+ * reference code it stands for. Plain pointers and sizes only; every function
+ * returns 0 on success or a negative rt_status; no exception crosses the ABI.
+ * A context is bound to ONE GPU (one process per GPU) and is not thread-safe.
+ */
+#ifndef RTGPU_H
+#define RTGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,        /* null / out-of-range argument */
+    RT_ERR_STATE = -2,      /* call order (no scene, no camera, no frame) */
+    RT_ERR_DEVICE = -3,     /* HIP runtime error; see rt_last_error */
+    RT_ERR_LIMIT = -4,      /* a documented limit is exceeded (tree depth, max_depth, counts) */
+    RT_ERR_NOMEM = -5
+};
+
+/* Material.h:10-15 */
+enum rt_material_type { RT_MAT_DIFFUSE = 0, RT_MAT_GLASS = 1, RT_MAT_MIRROR = 2, RT_MAT_CHECKER = 3 };
+
+/* Material.h:18-47, the fields Scene::rayTraceRecursive reads (Scene.h:174-280). */
+typedef struct {
+    float ka[3], kd[3], ks[3];
+    float pad0;
+    double shininess;       /* Material.h:22 is a double; set 0.0 where the reference leaves it unset */
+    int32_t type;           /* rt_material_type */
+    float ior;              /* index_medium */
+    float transparency;
+    float reflectivity;
+} rt_material;
+
+/* Scene.h:20-34 (Light): spherical area light. */
+typedef struct { float pos[3]; float radius; float color[3]; float pad0; } rt_light;
+
+/* Square.h:62-71 reads vertices[0], [1], [3] of the transformed quad. */
+typedef struct { float v0[3], v1[3], v3[3]; int32_t material; } rt_square;
+/* Sphere.h:39-40 */
+typedef struct { float center[3]; float radius; int32_t material; int32_t pad0[3]; } rt_sphere;
+
+/* Flattened BVH_Node (AccelerationStruct.h:97-143): one 64-byte record per INNER node
+ * holding both child boxes. Child link >= 0: inner node index (local to its tree);
+ * link < 0: leaf number -1-link (local to its tree). */
+typedef struct {
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad0[2];
+} rt_bvh_node;
+typedef struct { uint32_t first, count; } rt_bvh_leaf;   /* range of the tree's item array */
+
+/* RayTraceMesh (Mesh.h:210-227): ranges into the scene-wide arrays. */
+typedef struct {
+    int64_t vert_first, vert_count;     /* positions / normals (Mesh.h:26-42) */
+    int64_t tri_first, tri_count;       /* vertex-index triples (Mesh.h:44-63), indices local to the mesh */
+    int64_t node_first, node_count;     /* rt_bvh_node */
+    int64_t leaf_first, leaf_count;     /* rt_bvh_leaf; leaf item ranges are local to [tri_first, +tri_count) of mesh_items */
+    int32_t root;                       /* link of the root (a leaf link when the tree is a single leaf) */
+    int32_t material;
+    int32_t depth;                      /* tree depth (<= RT_MAX_TREE_DEPTH) */
+    int32_t pad0;
+} rt_mesh;
+
+#define RT_MAX_TREE_DEPTH 40
+#define RT_MAX_TOP_DEPTH 16
+#define RT_MAX_LIGHTS 16
+#define RT_MAX_PATH_DEPTH 60
+
+/* Flat description of a Scene (Scene.h:42-51) after Scene::applySettings (Scene.h:54-58)
+ * and BVH_Node::buildBVH (AccelerationStruct.cpp:91-148). The library copies everything;
+ * the caller keeps ownership. Object ordinals count squares, then spheres, then meshes
+ * (AccelerationStruct.cpp:123-134). */
+typedef struct {
+    int32_t n_materials;  const rt_material* materials;
+    int32_t n_lights;     const rt_light* lights;
+    int32_t n_squares;    const rt_square* squares;
+    int32_t n_spheres;    const rt_sphere* spheres;
+    int32_t n_meshes;     const rt_mesh* meshes;
+    int64_t n_verts;      const float* positions;  const float* normals;     /* 3 floats each */
+    int64_t n_tris;       const uint32_t* tri_indices;                       /* 3 per triangle */
+    const uint32_t* mesh_items;      /* n_tris entries: per mesh, triangle indices (local) in leaf order */
+    int64_t n_mesh_nodes; const rt_bvh_node* mesh_nodes;
+    int64_t n_mesh_leaves; const rt_bvh_leaf* mesh_leaves;
+    int32_t n_top_nodes;  const rt_bvh_node* top_nodes;
+    int32_t n_top_leaves; const rt_bvh_leaf* top_leaves;
+    int32_t n_top_items;  const uint32_t* top_items;                         /* object ordinals in leaf order */
+    int32_t top_root;     int32_t top_depth;
+} rt_scene_desc;
+
+/* Camera fields (Camera.h, Camera.cpp:24-38). rt_set_camera derives what Camera::apply
+ * (Camera.cpp:125-132), Camera::resize/gluPerspective (Camera.cpp:41-50) and the
+ * unprojection of matrixUtilities.h:188-222 compute through the GL matrix stacks. */
+typedef struct {
+    float x, y, z;          /* Camera::move */
+    float zoom;             /* _zoom */
+    float quat[4];          /* curquat -> build_rotmatrix, Trackball.cpp:323-345 */
+    float fovy_deg, aspect, znear, zfar;
+} rt_camera;
+
+/* The literals of the reference's render loop as parameters. */
+typedef struct {
+    int32_t img_w, img_h;       /* glutGet(GLUT_WINDOW_WIDTH/HEIGHT), main.cpp:184 */
+    int32_t spp;                /* nsamples, main.cpp:189 (30) */
+    int32_t max_depth;          /* Scene.h:284 (50) */
+    int32_t light_samples;      /* Scene.h:214 (35) */
+    int32_t shadow_mode;        /* 0 soft = sampleSphereLight (Scene.h:214); 1 hard = isInShadow per light (Scene.h:215) */
+    int32_t jitter;             /* 0 pixel centre; 1 counter-RNG jitter in place of rand() (main.cpp:195-196) */
+    uint32_t seed;
+} rt_render_params;
+
+typedef struct {
+    uint64_t rays_primary, rays_secondary, rays_shadow;   /* one ray = one BVH_Node::intersectObjects query */
+    uint64_t nonfinite;         /* radiance contributions that were NaN/Inf (dropped from the sum) */
+    uint64_t iterations;        /* wavefront iterations */
+    uint64_t pad0;
+    double ms_total;            /* device time of the frame (HIP events) */
+    double ms_closest;          /* sum over launches of the closest-hit+shade kernel */
+    double ms_shadow;           /* sum over launches of the shadow kernel */
+    uint64_t launches_closest, launches_shadow;
+    uint64_t peak_states;       /* high-water mark of the path-state stack */
+} rt_stats;
+
+/* One closest-hit result, RayIntersection (Ray.h:13-24) + identity. */
+typedef struct {
+    int32_t exists;
+    int32_t obj;            /* object ordinal, -1 = miss */
+    int32_t tri;            /* index into Mesh::triangles (0 for spheres/squares) */
+    float t;
+    float pos[3];
+    float nrm[3];
+    float u, v;
+} rt_hit;
+
+/* Creates a context on device_ids[0]. n_devices must be 1: scaling is one process per GPU
+ * (tiles are sharded by the caller, frames gathered with RCCL outside this library). */
+int rt_init(const int* device_ids, int n_devices, rt_ctx** out);
+void rt_shutdown(rt_ctx*);
+const char* rt_last_error(const rt_ctx*);
+
+/* Replaces the in-memory Scene the CPU path reads (Scene.h:42-51). */
+int rt_upload_scene(rt_ctx*, const rt_scene_desc*);
+/* camera.apply() + the GL read-back of matrixUtilities.h:188-217. */
+int rt_set_camera(rt_ctx*, const rt_camera*);
+/* Starts a frame: allocates/clears the img_w x img_h accumulator (std::vector<Vec3> image, main.cpp:203). */
+int rt_begin_frame(rt_ctx*, const rt_render_params*);
+/* Queues the pixels [x0,x0+w) x [y0,y0+h) (the per-pixel ThreadPool tasks of main.cpp:210-225).
+ * Asynchronous: the work runs at the next rt_download_framebuffer / rt_resolve_device / rt_flush. */
+int rt_render_tile(rt_ctx*, int x0, int y0, int w, int h);
+/* Runs all queued tiles to completion on the device. */
+int rt_flush(rt_ctx*);
+/* pixel_color /= nsamples (main.cpp:219) for the whole image, rows top to bottom, into host memory.
+ * prim_id (optional): 2 x uint32 per pixel = (object ordinal, triangle index) of sample 0's primary hit,
+ * 0xFFFFFFFF = miss or pixel not rendered. stats optional. */
+int rt_download_framebuffer(rt_ctx*, float* rgb, uint32_t* prim_id, rt_stats* stats);
+/* Same resolve, into DEVICE memory of the caller (img_w*img_h*3 floats), for RCCL gathers. */
+int rt_resolve_device(rt_ctx*, void* d_rgb);
+int rt_get_stats(rt_ctx*, rt_stats* stats);
+
+/* Fine-grained seams, host arrays in and out:
+ * Scene::computeIntersection (Scene.h:84-88) on n rays (origin, direction as given to Ray()). */
+int rt_intersect(rt_ctx*, const float* org, const float* dir, int64_t n, rt_hit* out);
+/* Scene::isInShadow (Scene.h:160-168) on n (point, light position) pairs. */
+int rt_occluded(rt_ctx*, const float* pts, const float* light_pos, int64_t n, int32_t* out);
+/* Scene::rayTrace (Scene.h:283-286) on n rays; pixel/sample key the light-sampling RNG. */
+int rt_trace(rt_ctx*, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample,
+             int64_t n, const rt_render_params*, float* rgb);
+/* Primary rays of a tile exactly as the render kernels generate them (w*h*spp, sample-minor). */
+int rt_camera_rays(rt_ctx*, const rt_render_params*, int x0, int y0, int w, int h, float* org, float* dir);
+
+/* Counter RNG that replaces random()/rand() (Scene.h:115-116, main.cpp:195-196). */
+uint32_t rt_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code, uint32_t light, uint32_t i, uint32_t which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -898,20 +898,34 @@ void mat4_mul(const double* a, const double* b, double* o) {   /* column-major a
             o[c * 4 + r] = s;
         }
 }
-bool mat4_inv(const double* m, double* inv) {                  /* Gauss-Jordan, partial pivoting */
-    double a[4][8];
-    for (int r = 0; r < 4; r++)
-        for (int c = 0; c < 4; c++) { a[r][c] = m[c * 4 + r]; a[r][c + 4] = (r == c) ? 1.0 : 0.0; }
-    for (int i = 0; i < 4; i++) {
-        int p = i;
-        for (int r = i + 1; r < 4; r++) if (std::fabs(a[r][i]) > std::fabs(a[p][i])) p = r;
-        if (a[p][i] == 0.0) return false;
-        if (p != i) for (int c = 0; c < 8; c++) std::swap(a[p][c], a[i][c]);
-        double d = a[i][i];
-        for (int c = 0; c < 8; c++) a[i][c] /= d;
-        for (int r = 0; r < 4; r++) if (r != i) { double f = a[r][i]; for (int c = 0; c < 8; c++) a[r][c] -= f * a[i][c]; }
-    }
-    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) inv[c * 4 + r] = a[r][c + 4];
+/* gluInvertMatrix, matrixUtilities.h:7-135: inv[4*b+a] is the cofactor of element (a,b) of
+ * M[r][c] = m[4r+c], written in the reference as six triple products: expansion along the
+ * first remaining column, each product evaluated left to right, terms added left to right.
+ * This restates that evaluation order with index arithmetic instead of 96 literal lines. */
+bool mat4_inv(const double* m, double* out) {
+    double inv[16];
+    auto M = [&](int r, int c) { return m[4 * r + c]; };
+    for (int a = 0; a < 4; a++)
+        for (int b = 0; b < 4; b++) {
+            int rows[3], cols[3];
+            for (int k = 0, i = 0, j = 0; k < 4; k++) { if (k != a) rows[i++] = k; if (k != b) cols[j++] = k; }
+            const int pairs[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+            double parity = ((a + b) % 2 == 0) ? 1.0 : -1.0;
+            double acc = 0.0;
+            for (int k = 0; k < 3; k++) {
+                double lead = M(rows[k], cols[0]);
+                if ((k == 1) == (parity > 0)) lead = -lead;      /* sign of the first term of this pair */
+                int ra = rows[pairs[k][0]], rb = rows[pairs[k][1]];
+                double plus = lead * M(ra, cols[1]) * M(rb, cols[2]);
+                double minus = (-lead) * M(ra, cols[2]) * M(rb, cols[1]);
+                acc = (k == 0) ? (plus + minus) : ((acc + plus) + minus);
+            }
+            inv[4 * b + a] = acc;
+        }
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0) return false;
+    det = 1.0 / det;
+    for (int i = 0; i < 16; i++) out[i] = inv[i] * det;
     return true;
 }
 void rotmatrix(const float q[4], float m[16]) {               /* Trackball.cpp:323-345 */
@@ -953,10 +967,14 @@ void camera_matrices(const orc_camera& cam, CamMats& cm) {
     for (int i = 0; i < 16; i++) rm[i] = rf[i];                /* glMultMatrixf reads m[4][4] as column-major */
     mat4_mul(t1, t2, a);
     mat4_mul(a, rm, mv);
-    double f = 1.0 / std::tan((double)cam.fovy_deg * M_PI / 360.0);
-    double zn = cam.znear, zf = cam.zfar;
+    /* gluPerspective as libGLU computes it: cotangent = cos/sin of fovy/2, deltaZ = zFar - zNear */
+    double radians = (double)cam.fovy_deg / 2.0 * M_PI / 180.0;
+    double cotangent = std::cos(radians) / std::sin(radians);
+    double deltaZ = (double)cam.zfar - (double)cam.znear;
     double p[16] = {0};
-    p[0] = f / (double)cam.aspect; p[5] = f; p[10] = (zf + zn) / (zn - zf); p[11] = -1.0; p[14] = 2.0 * zf * zn / (zn - zf);
+    p[0] = cotangent / (double)cam.aspect; p[5] = cotangent;
+    p[10] = -((double)cam.zfar + (double)cam.znear) / deltaZ; p[11] = -1.0;
+    p[14] = -2.0 * (double)cam.znear * (double)cam.zfar / deltaZ;
     mat4_inv(p, cm.pinv);
     mat4_inv(mv, cm.mvinv);
     double r[4];

@@ -1,0 +1,679 @@
+/*
+ * scene.cpp -- host-side mirror of the reference's Scene / Mesh / Square / Sphere /
+ * Camera types, its two BVH builders and its render entry point (see rthost.h).
+ * Product code: never includes or calls anything under oracle/.
+ *
+ * Float arithmetic follows the reference's operation order (compile with
+ * -ffp-contract=off) so that the flattened scene is bit-identical to what the CPU
+ * path would hold in memory.
+ */
+#include "rthost.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+namespace rth {
+
+static std::string g_asset_dir = "assets/models";
+void set_asset_dir(const std::string& dir) { g_asset_dir = dir; }
+
+/* ------------------------------------------------------------------ Vec3.h */
+float Vec3::squareLength() const { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }          /* Vec3.h:29 */
+float Vec3::length() const { return (float)::sqrt((double)squareLength()); }                  /* Vec3.h:32 (double sqrt) */
+void Vec3::normalize() { float L = length(); v[0] /= L; v[1] /= L; v[2] /= L; }               /* Vec3.h:37 */
+float Vec3::dot(const Vec3& a, const Vec3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+Vec3 Vec3::cross(const Vec3& a, const Vec3& b) {
+    return Vec3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+}
+Vec3 operator+(const Vec3& a, const Vec3& b) { return Vec3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+Vec3 operator-(const Vec3& a, const Vec3& b) { return Vec3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+Vec3 operator*(float s, const Vec3& a) { return Vec3(s * a[0], s * a[1], s * a[2]); }
+Vec3 operator*(const Vec3& a, float s) { return Vec3(s * a[0], s * a[1], s * a[2]); }
+Vec3 operator/(const Vec3& a, float s) { return Vec3(a[0] / s, a[1] / s, a[2] / s); }
+Vec3 Mat3::operator*(const Vec3& p) const {                                                    /* Vec3.h:156-163 */
+    return Vec3(m[0] * p[0] + m[1] * p[1] + m[2] * p[2],
+                m[3] * p[0] + m[4] * p[1] + m[5] * p[2],
+                m[6] * p[0] + m[7] * p[1] + m[8] * p[2]);
+}
+
+AABB::AABB() : min(INFINITY), max(-INFINITY) {}                                                /* AccelerationStruct.h:29-32 */
+Vec3 AABB::getCenter() const { return (min + max) / 2.f; }                                     /* AccelerationStruct.cpp:32-34 */
+
+/* ------------------------------------------------------------------ Mesh */
+bool Mesh::loadOFF(const std::string& filename) {
+    std::ifstream in(filename.c_str());
+    if (!in) return false;                 /* the reference exits the process here (Mesh.cpp:7-8) */
+    std::string header;
+    unsigned int sizeV = 0, sizeT = 0, tmp = 0;
+    in >> header >> sizeV >> sizeT >> tmp;
+    positions.assign(sizeV, Vec3());
+    triangles.assign(3 * (size_t)sizeT, 0u);
+    for (unsigned int i = 0; i < sizeV; i++) in >> positions[i][0] >> positions[i][1] >> positions[i][2];
+    for (unsigned int i = 0; i < sizeT; i++) {
+        int s;
+        in >> s;
+        for (unsigned int j = 0; j < 3; j++) in >> triangles[3 * (size_t)i + j];
+    }
+    return true;
+}
+
+void Mesh::recomputeNormals() {
+    normals.assign(positions.size(), Vec3(0.f, 0.f, 0.f));
+    const size_t nt = triangleCount();
+    for (size_t t = 0; t < nt; t++) {
+        const uint32_t i0 = triangles[3 * t], i1 = triangles[3 * t + 1], i2 = triangles[3 * t + 2];
+        Vec3 n = Vec3::cross(positions[i1] - positions[i0], positions[i2] - positions[i0]);
+        n.normalize();
+        normals[i0] = normals[i0] + n;
+        normals[i1] = normals[i1] + n;
+        normals[i2] = normals[i2] + n;
+    }
+    for (Vec3& n : normals) n.normalize();
+}
+
+void Mesh::centerAndScaleToUnit() {
+    Vec3 c(0.f, 0.f, 0.f);
+    for (const Vec3& p : positions) c = c + p;
+    c = c / (float)positions.size();
+    float maxD = (positions[0] - c).length();
+    for (const Vec3& p : positions) {
+        float m = (p - c).length();
+        if (m > maxD) maxD = m;
+    }
+    for (Vec3& p : positions) p = (p - c) / maxD;
+}
+
+void Mesh::translate(const Vec3& t) { for (Vec3& p : positions) p = p + t; }
+void Mesh::apply_transformation_matrix(const Mat3& t) { for (Vec3& p : positions) p = t * p; }
+static Mat3 scaleMatrix(const Vec3& s) { return Mat3{{s[0], 0.f, 0.f, 0.f, s[1], 0.f, 0.f, 0.f, s[2]}}; }
+/* angle * M_PI / 180. is evaluated in double and narrowed; cos/sin are the double versions (Mesh.h:151-173). */
+static void angleCosSin(float angle, float& c, float& s) {
+    float a = (float)((double)angle * M_PI / 180.);
+    c = (float)::cos((double)a);
+    s = (float)::sin((double)a);
+}
+static Mat3 rotX(float angle) { float c, s; angleCosSin(angle, c, s); return Mat3{{1.f, 0.f, 0.f, 0.f, c, -s, 0.f, s, c}}; }
+static Mat3 rotY(float angle) { float c, s; angleCosSin(angle, c, s); return Mat3{{c, 0.f, s, 0.f, 1.f, 0.f, -s, 0.f, c}}; }
+static Mat3 rotZ(float angle) { float c, s; angleCosSin(angle, c, s); return Mat3{{c, -s, 0.f, s, c, 0.f, 0.f, 0.f, 1.f}}; }
+void Mesh::scale(const Vec3& s) { apply_transformation_matrix(scaleMatrix(s)); }
+void Mesh::rotate_x(float angle) { apply_transformation_matrix(rotX(angle)); }
+void Mesh::rotate_y(float angle) { apply_transformation_matrix(rotY(angle)); }
+void Mesh::rotate_z(float angle) { apply_transformation_matrix(rotZ(angle)); }
+void Mesh::buildTree(unsigned nb) { buildBVH(positions, triangles, (int)nb, triangleTree); }
+
+/* ------------------------------------------------------------------ Square / Sphere */
+void Square::setQuad(const Vec3& bottomLeft, const Vec3& rightVector, const Vec3& upVector, float width, float height) {
+    Vec3 r = rightVector, u = upVector;          /* Square.h:33-43 */
+    r.normalize();
+    u.normalize();
+    r = r * width;
+    u = u * height;
+    vertices[0] = bottomLeft;                    /* Square.h:47-50 */
+    vertices[1] = bottomLeft + r;
+    vertices[2] = bottomLeft + r + u;
+    vertices[3] = bottomLeft + u;
+}
+void Square::translate(const Vec3& t) { for (Vec3& p : vertices) p = p + t; }
+void Square::scale(const Vec3& s) { Mat3 m = scaleMatrix(s); for (Vec3& p : vertices) p = m * p; }
+void Square::rotate_x(float angle) { Mat3 m = rotX(angle); for (Vec3& p : vertices) p = m * p; }
+AABB Square::getBoundingBox() const {
+    Vec3 mn = vertices[0], mx = vertices[0];
+    for (const Vec3& p : vertices)
+        for (int i = 0; i < 3; i++) { mn[i] = std::min(mn[i], p[i]); mx[i] = std::max(mx[i], p[i]); }
+    return AABB(mn, mx);
+}
+AABB Sphere::getBoundingBox() const { Vec3 d(m_radius); return AABB(m_center - d, m_center + d); }
+
+rt_camera Camera::pack() const {
+    rt_camera c;
+    c.x = x; c.y = y; c.z = z; c.zoom = _zoom;
+    for (int i = 0; i < 4; i++) c.quat[i] = curquat[i];
+    c.fovy_deg = fovAngle; c.aspect = aspectRatio; c.znear = nearPlane; c.zfar = farPlane;
+    return c;
+}
+
+/* ------------------------------------------------------------------ BVH builders
+ * Both builders work in place on one array of build records and emit the flattened
+ * tree directly. The reference partitions with std::partition on a random-access
+ * range and then copies both halves (AccelerationStruct.cpp:164-170,210-216); the
+ * element order after that call is what fixes leaf order, so `split` below performs
+ * the same sequence of swaps (scan from the left for the first element failing the
+ * predicate, from the right for the last one passing it, swap, repeat). */
+template <class Rec, class Pred>
+static size_t split(Rec* a, size_t lo, size_t hi, Pred pred) {
+    size_t first = lo, last = hi;
+    for (;;) {
+        for (;;) {
+            if (first == last) return first;
+            if (pred(a[first])) ++first; else break;
+        }
+        --last;
+        for (;;) {
+            if (first == last) return first;
+            if (!pred(a[last])) --last; else break;
+        }
+        std::swap(a[first], a[last]);
+        ++first;
+    }
+}
+
+struct BuildRec { uint32_t index; float c[3]; float mn[3], mx[3]; };
+
+static AABB unionBox(const BuildRec* a, size_t lo, size_t hi) {      /* getBoundingBox, AccelerationStruct.cpp:57-69,77-89 */
+    AABB g(Vec3(a[lo].mn[0], a[lo].mn[1], a[lo].mn[2]), Vec3(a[lo].mx[0], a[lo].mx[1], a[lo].mx[2]));
+    for (size_t i = lo; i < hi; i++)
+        for (int k = 0; k < 3; k++) {
+            g.min[k] = std::min(g.min[k], a[i].mn[k]);
+            g.max[k] = std::max(g.max[k], a[i].mx[k]);
+        }
+    return g;
+}
+
+static int32_t emitLeaf(FlatTree& t, const BuildRec* a, size_t lo, size_t hi) {
+    rt_bvh_leaf lf;
+    lf.first = (uint32_t)t.items.size();
+    lf.count = (uint32_t)(hi - lo);
+    for (size_t i = lo; i < hi; i++) t.items.push_back(a[i].index);
+    t.leaves.push_back(lf);
+    return -(int32_t)t.leaves.size();            /* link = -1 - leafIndex */
+}
+static void storeBoxes(rt_bvh_node& n, const AABB& l, const AABB& r) {
+    for (int k = 0; k < 3; k++) { n.lmin[k] = l.min[k]; n.lmax[k] = l.max[k]; n.rmin[k] = r.min[k]; n.rmax[k] = r.max[k]; }
+}
+
+/* mode 0: triangle tree (longest axis, leaf when n<=1); mode 1: object tree (shared axis
+ * counter, leaf when n<=2). Returns the link of the subtree. */
+static int32_t buildNode(FlatTree& t, BuildRec* a, size_t lo, size_t hi, int deepLimit, const AABB& box, int mode,
+                         int& axisCounter, int level) {
+    const size_t n = hi - lo;
+    const size_t leafMax = mode == 0 ? 1 : 2;
+    if (!(deepLimit > 0 && n > leafMax)) {
+        t.depth = std::max(t.depth, level);
+        return emitLeaf(t, a, lo, hi);
+    }
+    Vec3 diag = box.max - box.min;
+    int axis;
+    if (mode == 0) {
+        axis = diag[0] > std::max(diag[1], diag[2]) ? 0 : diag[1] > diag[2] ? 1 : 2;   /* AccelerationStruct.cpp:160 */
+    } else {
+        axisCounter %= 3;                                                              /* AccelerationStruct.cpp:206 */
+        axis = axisCounter;
+    }
+    Vec3 center = box.min + diag / 2.f;
+    const float pivot = center[axis];
+    size_t mid = split(a, lo, hi, [axis, pivot](const BuildRec& r) { return r.c[axis] < pivot; });
+    if (mode == 1) axisCounter++;                                                      /* AccelerationStruct.cpp:222 */
+    const int32_t me = (int32_t)t.nodes.size();
+    t.nodes.emplace_back();
+    std::memset(&t.nodes[me], 0, sizeof(rt_bvh_node));
+    AABB lb, rb;                                  /* empty halves keep the inverted +-INF box */
+    int32_t l, r;
+    if (mid - lo >= 1) { lb = unionBox(a, lo, mid); l = buildNode(t, a, lo, mid, deepLimit - 1, lb, mode, axisCounter, level + 1); }
+    else l = buildNode(t, a, lo, lo, 0, lb, mode, axisCounter, level + 1);
+    if (hi - mid >= 1) { rb = unionBox(a, mid, hi); r = buildNode(t, a, mid, hi, deepLimit - 1, rb, mode, axisCounter, level + 1); }
+    else r = buildNode(t, a, mid, mid, 0, rb, mode, axisCounter, level + 1);
+    storeBoxes(t.nodes[me], lb, rb);
+    t.nodes[me].left = l;
+    t.nodes[me].right = r;
+    return me;
+}
+
+void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out) {
+    out = FlatTree();
+    const size_t nt = triangles.size() / 3;
+    std::vector<BuildRec> recs(nt);
+    for (size_t i = 0; i < nt; i++) {             /* BuildingTriangle, AccelerationStruct.cpp:36-55 */
+        const Vec3 &a = positions[triangles[3 * i]], &b = positions[triangles[3 * i + 1]], &c = positions[triangles[3 * i + 2]];
+        Vec3 avg = (a + b + c) / 3.f;
+        BuildRec& r = recs[i];
+        r.index = (uint32_t)i;
+        for (int k = 0; k < 3; k++) {
+            r.c[k] = avg[k];
+            float mn = a[k], mx = a[k];
+            mn = std::min(b[k], mn); mx = std::max(b[k], mx);
+            mn = std::min(c[k], mn); mx = std::max(c[k], mx);
+            r.mn[k] = mn; r.mx[k] = mx;
+        }
+    }
+    AABB box;                                     /* AccelerationStruct.cpp:103-110 */
+    for (const Vec3& p : positions)
+        for (int k = 0; k < 3; k++) {
+            box.min[k] = p[k] < box.min[k] ? p[k] : box.min[k];
+            box.max[k] = p[k] > box.max[k] ? p[k] : box.max[k];
+        }
+    out.rootBox = box;
+    out.items.reserve(nt);
+    int unused = 0;
+    out.root = buildNode(out, recs.data(), 0, nt, deepLimit, box, 0, unused, 0);
+}
+
+void buildBVH(const std::vector<AABB>& objectBoxes, int deepLimit, FlatTree& out) {
+    out = FlatTree();
+    std::vector<BuildRec> recs(objectBoxes.size());
+    AABB box;
+    for (size_t i = 0; i < objectBoxes.size(); i++) {
+        const AABB& b = objectBoxes[i];
+        Vec3 c = b.getCenter();                   /* predicate of AccelerationStruct.cpp:212 */
+        recs[i].index = (uint32_t)i;
+        for (int k = 0; k < 3; k++) {
+            recs[i].c[k] = c[k]; recs[i].mn[k] = b.min[k]; recs[i].mx[k] = b.max[k];
+            box.min[k] = std::min(box.min[k], b.min[k]);                               /* AccelerationStruct.cpp:138-145 */
+            box.max[k] = std::max(box.max[k], b.max[k]);
+        }
+    }
+    out.rootBox = box;
+    int axisCounter = 0;                          /* comparisonIdx = 0, AccelerationStruct.h:122 */
+    out.root = buildNode(out, recs.data(), 0, recs.size(), deepLimit, box, 1, axisCounter, 0);
+}
+
+/* ------------------------------------------------------------------ Scene */
+void Scene::clear() { meshes.clear(); spheres.clear(); squares.clear(); lights.clear(); sceneBvh = FlatTree(); }
+void Scene::applySettings(Settings set) { for (Mesh& m : meshes) m.buildTree(set.tree_subdivide); }
+void Scene::buildSceneBvh() {
+    std::vector<AABB> boxes;                      /* squares, spheres, meshes: AccelerationStruct.cpp:123-134 */
+    for (const Square& s : squares) boxes.push_back(s.getBoundingBox());
+    for (const Sphere& s : spheres) boxes.push_back(s.getBoundingBox());
+    for (const Mesh& m : meshes) boxes.push_back(m.getBoundingBox());
+    buildBVH(boxes, topDepthLimit, sceneBvh);
+}
+
+static Light pointLight(float x, float y, float z, float radius) {
+    Light l; l.pos = Vec3(x, y, z); l.radius = radius; l.material = Vec3(1.f, 1.f, 1.f); return l;
+}
+/* The floor quad every scene uses: setQuad, translate(0,0,-2), scale(sx,sy,1), rotate_x(-90). */
+static Square floorQuad(float sx, float sy) {
+    Square s;
+    s.setQuad(Vec3(-1.f, -1.f, 0.f), Vec3(1.f, 0.f, 0.f), Vec3(0.f, 1.f, 0.f), 2.f, 2.f);
+    s.translate(Vec3(0.f, 0.f, -2.f));
+    s.scale(Vec3(sx, sy, 1.f));
+    s.rotate_x(-90.f);
+    return s;
+}
+static void setColour(Material& m, float r, float g, float b, double shininess) {
+    m.diffuse_material = Vec3(r, g, b); m.specular_material = Vec3(r, g, b); m.shininess = shininess;
+}
+
+bool Scene::setup_refraction_scene() {
+    clear();
+    lights.push_back(pointLight(0.0f, 3.5f, 0.0f, .5f));
+    Square s = floorQuad(80.f, 80.f);
+    setColour(s.material, 0.75f, 1.f, 0.75f, 16);
+    s.material.type = RT_MAT_CHECKER;
+    squares.push_back(s);
+    Sphere g;
+    g.m_center = Vec3(0.f, 0.f, 0.5f); g.m_radius = 0.75f;
+    g.material.type = RT_MAT_GLASS;
+    setColour(g.material, 1.f, 0.f, 0.f, 16);
+    g.material.transparency = 0.1f; g.material.index_medium = 1.4f;
+    spheres.push_back(g);
+    buildSceneBvh();
+    return true;
+}
+bool Scene::setup_reflexion_scene() {
+    clear();
+    lights.push_back(pointLight(0.0f, 3.5f, 0.0f, .5f));
+    Square s = floorQuad(80.f, 80.f);
+    setColour(s.material, 0.75f, 1.f, 0.75f, 16);
+    s.material.type = RT_MAT_CHECKER;
+    squares.push_back(s);
+    Sphere g;
+    g.m_center = Vec3(0.f, -1.25f, 0.5f); g.m_radius = 0.75f;
+    g.material.type = RT_MAT_MIRROR;
+    setColour(g.material, 0.75f, 1.f, 1.f, 16);
+    g.material.transparency = 1.0f; g.material.index_medium = 1.4f; g.material.reflectivity = 0.5f;
+    spheres.push_back(g);
+    buildSceneBvh();
+    return true;
+}
+bool Scene::setup_mesh_scene(const std::string& off, bool unit) {
+    clear();
+    lights.push_back(pointLight(1.0f, 2.5f, 0.0f, .5f));           /* Scene.h:722-731 */
+    Square f = floorQuad(2.f, 2.f);                                 /* Scene.h:733-744 */
+    setColour(f.material, 1.f, 1.f, 1.f, 16);
+    squares.push_back(f);
+    Square w;                                                       /* Scene.h:746-756 */
+    w.setQuad(Vec3(-1.f, -1.f, 0.f), Vec3(1.f, 0.f, 0.f), Vec3(0.f, 1.f, 0.f), 2.f, 2.f);
+    w.scale(Vec3(2.f, 2.f, 1.f));
+    w.translate(Vec3(0.f, 0.f, -2.f));
+    setColour(w.material, 0.5f, 0.f, 0.5f, 16);
+    squares.push_back(w);
+    meshes.emplace_back();                                          /* Scene.h:768-781 */
+    Mesh& m = meshes.back();
+    if (!m.loadOFF(g_asset_dir + "/" + off)) return false;
+    if (unit) m.centerAndScaleToUnit(); else m.scale(Vec3(0.0125f));
+    m.translate(Vec3(0.f, -1.05f, 0.f));
+    m.build_arrays();
+    setColour(m.material, 1.f, 1.f, 1.f, 16);
+    m.buildTree(3);
+    buildSceneBvh();
+    return true;
+}
+
+static float rand01() { return (float)rand() / (float)RAND_MAX; }
+
+bool Scene::setup_final_scene() {
+    clear();
+    srand(1);     /* main() sets this scene up first, from glibc's default seed (main.cpp:387-393) */
+    static const float nice[10][2][3] = {
+        {{1.0f, 0.0f, 0.0f}, {0.5f, 0.0f, 0.0f}}, {{0.0f, 1.0f, 0.0f}, {0.0f, 0.5f, 0.0f}},
+        {{0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 0.5f}}, {{1.0f, 1.0f, 0.0f}, {0.5f, 0.5f, 0.0f}},
+        {{1.0f, 0.5f, 0.0f}, {0.5f, 0.25f, 0.0f}}, {{0.5f, 0.0f, 1.0f}, {0.25f, 0.0f, 0.5f}},
+        {{0.0f, 1.0f, 1.0f}, {0.0f, 0.5f, 0.5f}}, {{1.0f, 0.0f, 1.0f}, {0.5f, 0.0f, 0.5f}},
+        {{0.5f, 0.5f, 0.5f}, {0.25f, 0.25f, 0.25f}}, {{1.0f, 1.0f, 1.0f}, {0.5f, 0.5f, 0.5f}}};
+    lights.push_back(pointLight(4.0f, 0.f, 10.f, .5f));
+    lights.push_back(pointLight(-6.f, 2.f, 1.25f, 10.75f));
+    {
+        Square s = floorQuad(20.f, 20.f);
+        setColour(s.material, 1.f, 1.f, 1.f, 16);
+        s.material.type = RT_MAT_CHECKER;
+        squares.push_back(s);
+    }
+    {
+        meshes.emplace_back();
+        Mesh& m = meshes.back();
+        if (!m.loadOFF(g_asset_dir + "/gorilla18_fixed.obj.off")) return false;
+        m.scale(Vec3(0.04f));
+        m.translate(Vec3(-5.f, -1.9f, 0.f));
+        m.build_arrays();
+        m.material.type = RT_MAT_GLASS;
+        setColour(m.material, 1.f, 0.f, 0.f, 16);
+        m.material.transparency = 1.0f; m.material.index_medium = 1.4f;
+    }
+    {
+        Sphere s;
+        s.m_center = Vec3(-4.f, 0.f, 7.f); s.m_radius = 1.75f;
+        s.material.diffuse_material = Vec3(nice[0][0][0], nice[0][0][1], nice[0][0][2]);
+        s.material.specular_material = Vec3(nice[0][1][0], nice[0][1][1], nice[0][1][2]);
+        s.material.type = RT_MAT_GLASS; s.material.transparency = 0.8f; s.material.index_medium = 1.3f;
+        spheres.push_back(s);
+    }
+    {
+        Sphere s;
+        s.m_center = Vec3(0.f); s.m_radius = 3.75f;
+        s.material.type = RT_MAT_MIRROR;
+        s.material.diffuse_material = Vec3(1.f, 1.f, 1.f); s.material.specular_material = Vec3(1.f, 1.f, 1.f);
+        s.material.reflectivity = 0.9f;
+        spheres.push_back(s);
+    }
+    Mesh flamingo;
+    if (!flamingo.loadOFF(g_asset_dir + "/flamingo.off")) return false;
+    for (int i = 0; i < 30; i++) {
+        meshes.push_back(flamingo);
+        Mesh& m = meshes.back();
+        float randZ = (float)((double)rand01() * 50. - 25.);
+        m.scale(Vec3(0.0125f));
+        m.translate(Vec3(0.f, -2.f, randZ));
+        m.rotate_y((float)((double)rand01() * 360.));
+        m.build_arrays();
+        setColour(m.material, 1.f, 0.753f, 0.796f, 16);
+    }
+    for (int i = 0; i < 50; i++) {
+        Sphere s;
+        s.m_radius = (float)((double)rand01() + 0.5);
+        float randZ = (float)((double)rand01() * 50. - 25.);
+        float randX = (float)((double)rand01() * 50. - 25.);
+        float randY = (float)((double)rand01() * 20. - 2.);
+        s.m_center = Vec3(randX, randY, randZ);
+        rand(); rand(); rand();                                     /* the unused randColor, Scene.h:947 */
+        int c = rand() % 10;
+        s.material.diffuse_material = Vec3(nice[c][0][0], nice[c][0][1], nice[c][0][2]);
+        s.material.specular_material = Vec3(nice[c][1][0], nice[c][1][1], nice[c][1][2]);
+        s.material.shininess = rand() % 16;
+        int randType = rand() % 3;
+        if (randType == 0) {
+            s.material.type = RT_MAT_GLASS;
+            s.material.transparency = (float)(rand() / RAND_MAX);   /* integer division as written, Scene.h:959 */
+        } else if (randType == 1) {
+            s.material.type = RT_MAT_MIRROR;
+            s.material.reflectivity = (float)(rand() / RAND_MAX * 0.5 + 0.5);
+            s.material.transparency = (float)(rand() / RAND_MAX * 0.5 + 0.5);
+        }
+        spheres.push_back(s);
+    }
+    for (Mesh& m : meshes) m.buildTree(3);                          /* build_arrays -> buildTree(), Mesh.h:216-219 */
+    buildSceneBvh();
+    return true;
+}
+
+/* Counter RNG of rtgpu (rt_rng) drives the synthetic soup so that both sides of the
+ * boundary can generate it without files. */
+static float unit24(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+bool Scene::setup_soup_scene(int64_t ntris) {
+    clear();
+    lights.push_back(pointLight(0.f, 8.f, 0.f, .5f));
+    Square f = floorQuad(2.f, 2.f);
+    setColour(f.material, 1.f, 1.f, 1.f, 16);
+    squares.push_back(f);
+    meshes.emplace_back();
+    Mesh& m = meshes.back();
+    m.positions.resize((size_t)ntris * 3);
+    m.triangles.resize((size_t)ntris * 3);
+    for (int64_t k = 0; k < ntris; k++) {
+        float r[9];
+        for (uint32_t j = 0; j < 9; j++) r[j] = unit24(rt_rng(1u, (uint32_t)k, (uint32_t)(k >> 32), 0, 0xFFFFFFFEu, j, 0));
+        Vec3 c(-8.f + 16.f * r[0], -2.f + 8.f * r[1], -8.f + 16.f * r[2]);
+        Vec3 e1(-0.02f + 0.04f * r[3], -0.02f + 0.04f * r[4], -0.02f + 0.04f * r[5]);
+        Vec3 e2(-0.02f + 0.04f * r[6], -0.02f + 0.04f * r[7], -0.02f + 0.04f * r[8]);
+        m.positions[3 * k] = c;
+        m.positions[3 * k + 1] = c + e1;
+        m.positions[3 * k + 2] = c + e2;
+        for (int j = 0; j < 3; j++) m.triangles[3 * k + j] = (uint32_t)(3 * k + j);
+    }
+    m.build_arrays();
+    setColour(m.material, 0.8f, 0.8f, 0.8f, 16);
+    m.buildTree(3);
+    buildSceneBvh();
+    return true;
+}
+
+bool Scene::setup(const std::string& name) {
+    if (name == "final") return setup_final_scene();
+    if (name == "refraction") return setup_refraction_scene();
+    if (name == "reflexion") return setup_reflexion_scene();
+    if (name == "mesh_gorilla") return setup_mesh_scene("gorilla18_fixed.obj.off", false);
+    if (name == "mesh_cow") return setup_mesh_scene("cow.off", true);
+    if (name.rfind("soup:", 0) == 0) return setup_soup_scene(atoll(name.c_str() + 5));
+    return false;
+}
+
+static int32_t addMaterial(std::vector<rt_material>& out, const Material& m) {
+    rt_material r;
+    std::memset(&r, 0, sizeof(r));
+    for (int k = 0; k < 3; k++) { r.ka[k] = m.ambient_material[k]; r.kd[k] = m.diffuse_material[k]; r.ks[k] = m.specular_material[k]; }
+    r.shininess = m.shininess; r.type = m.type; r.ior = m.index_medium; r.transparency = m.transparency; r.reflectivity = m.reflectivity;
+    out.push_back(r);
+    return (int32_t)out.size() - 1;
+}
+
+const rt_scene_desc& Scene::flatten() {
+    f_materials.clear(); f_lights.clear(); f_squares.clear(); f_spheres.clear(); f_meshes.clear();
+    f_positions.clear(); f_normals.clear(); f_tris.clear(); f_items.clear(); f_nodes.clear(); f_leaves.clear();
+    for (const Light& l : lights) {
+        rt_light r;
+        std::memset(&r, 0, sizeof(r));
+        for (int k = 0; k < 3; k++) { r.pos[k] = l.pos[k]; r.color[k] = l.material[k]; }
+        r.radius = l.radius;
+        f_lights.push_back(r);
+    }
+    for (const Square& s : squares) {
+        rt_square r;
+        for (int k = 0; k < 3; k++) { r.v0[k] = s.vertices[0][k]; r.v1[k] = s.vertices[1][k]; r.v3[k] = s.vertices[3][k]; }
+        r.material = addMaterial(f_materials, s.material);
+        f_squares.push_back(r);
+    }
+    for (const Sphere& s : spheres) {
+        rt_sphere r;
+        std::memset(&r, 0, sizeof(r));
+        for (int k = 0; k < 3; k++) r.center[k] = s.m_center[k];
+        r.radius = s.m_radius;
+        r.material = addMaterial(f_materials, s.material);
+        f_spheres.push_back(r);
+    }
+    size_t nv = 0, nt = 0, nn = 0, nl = 0;
+    for (const Mesh& m : meshes) { nv += m.positions.size(); nt += m.triangleCount(); nn += m.triangleTree.nodes.size(); nl += m.triangleTree.leaves.size(); }
+    f_positions.reserve(3 * nv); f_normals.reserve(3 * nv); f_tris.reserve(3 * nt); f_items.reserve(nt);
+    f_nodes.reserve(nn); f_leaves.reserve(nl);
+    for (const Mesh& m : meshes) {
+        rt_mesh r;
+        std::memset(&r, 0, sizeof(r));
+        r.vert_first = (int64_t)f_positions.size() / 3; r.vert_count = (int64_t)m.positions.size();
+        r.tri_first = (int64_t)f_tris.size() / 3; r.tri_count = (int64_t)m.triangleCount();
+        r.node_first = (int64_t)f_nodes.size(); r.node_count = (int64_t)m.triangleTree.nodes.size();
+        r.leaf_first = (int64_t)f_leaves.size(); r.leaf_count = (int64_t)m.triangleTree.leaves.size();
+        r.root = m.triangleTree.root; r.depth = m.triangleTree.depth;
+        r.material = addMaterial(f_materials, m.material);
+        for (size_t i = 0; i < m.positions.size(); i++)
+            for (int k = 0; k < 3; k++) { f_positions.push_back(m.positions[i][k]); f_normals.push_back(m.normals[i][k]); }
+        f_tris.insert(f_tris.end(), m.triangles.begin(), m.triangles.end());
+        f_items.insert(f_items.end(), m.triangleTree.items.begin(), m.triangleTree.items.end());
+        f_nodes.insert(f_nodes.end(), m.triangleTree.nodes.begin(), m.triangleTree.nodes.end());
+        f_leaves.insert(f_leaves.end(), m.triangleTree.leaves.begin(), m.triangleTree.leaves.end());
+        f_meshes.push_back(r);
+    }
+    rt_scene_desc& d = f_desc;
+    std::memset(&d, 0, sizeof(d));
+    d.n_materials = (int32_t)f_materials.size(); d.materials = f_materials.data();
+    d.n_lights = (int32_t)f_lights.size(); d.lights = f_lights.data();
+    d.n_squares = (int32_t)f_squares.size(); d.squares = f_squares.data();
+    d.n_spheres = (int32_t)f_spheres.size(); d.spheres = f_spheres.data();
+    d.n_meshes = (int32_t)f_meshes.size(); d.meshes = f_meshes.data();
+    d.n_verts = (int64_t)nv; d.positions = f_positions.data(); d.normals = f_normals.data();
+    d.n_tris = (int64_t)nt; d.tri_indices = f_tris.data(); d.mesh_items = f_items.data();
+    d.n_mesh_nodes = (int64_t)f_nodes.size(); d.mesh_nodes = f_nodes.data();
+    d.n_mesh_leaves = (int64_t)f_leaves.size(); d.mesh_leaves = f_leaves.data();
+    d.n_top_nodes = (int32_t)sceneBvh.nodes.size(); d.top_nodes = sceneBvh.nodes.data();
+    d.n_top_leaves = (int32_t)sceneBvh.leaves.size(); d.top_leaves = sceneBvh.leaves.data();
+    d.n_top_items = (int32_t)sceneBvh.items.size(); d.top_items = sceneBvh.items.data();
+    d.top_root = sceneBvh.root; d.top_depth = sceneBvh.depth;
+    return d;
+}
+
+/* ------------------------------------------------------------------ render entry point */
+int write_ppm(const char* filename, const float* rgb, int w, int h) {
+    std::ofstream f(filename, std::ios::binary);
+    if (f.fail()) {
+        std::printf("Could not open file: %s\n", filename);
+        return RT_ERR_ARG;
+    }
+    f << "P3" << std::endl << w << " " << h << std::endl << 255 << std::endl;
+    for (int i = 0; i < w * h; i++)
+        f << (int)(255.f * std::min<float>(1.f, rgb[3 * i])) << " " << (int)(255.f * std::min<float>(1.f, rgb[3 * i + 1])) << " "
+          << (int)(255.f * std::min<float>(1.f, rgb[3 * i + 2])) << " ";
+    f << std::endl;
+    f.close();
+    return RT_OK;
+}
+
+int ray_trace_from_camera(rt_ctx* ctx, Scene& scene, const Camera& camera, int w, int h, const rt_render_params* prm,
+                          const char* filename, double* seconds) {
+    (void)scene;   /* the scene was handed over with rt_upload_scene(scene.flatten()) */
+    const auto startTime = std::chrono::high_resolution_clock::now();
+    std::printf("Ray tracing a %d x %d image on the GPU\n", w, h);
+    rt_render_params p;
+    if (prm) p = *prm;
+    else { p.img_w = w; p.img_h = h; p.spp = 30; p.max_depth = 50; p.light_samples = 35; p.shadow_mode = 0; p.jitter = 1; p.seed = 0; }
+    p.img_w = w; p.img_h = h;
+    rt_camera cam = camera.pack();
+    int rc;
+    if ((rc = rt_set_camera(ctx, &cam)) != RT_OK) return rc;
+    if ((rc = rt_begin_frame(ctx, &p)) != RT_OK) return rc;
+    const int T = 32;
+    for (int y = 0; y < h; y += T)
+        for (int x = 0; x < w; x += T)
+            if ((rc = rt_render_tile(ctx, x, y, std::min(T, w - x), std::min(T, h - y))) != RT_OK) return rc;
+    std::vector<float> image((size_t)w * h * 3);
+    if ((rc = rt_download_framebuffer(ctx, image.data(), nullptr, nullptr)) != RT_OK) return rc;
+    const auto stopTime = std::chrono::high_resolution_clock::now();
+    double secs = std::chrono::duration<double>(stopTime - startTime).count();
+    if (seconds) *seconds = secs;
+    std::printf("Done in: %.3fs\n", secs);
+    if (filename) return write_ppm(filename, image.data(), w, h);
+    return RT_OK;
+}
+
+}  // namespace rth
+
+/* ====================================================================== C facade */
+struct rth_scene { rth::Scene scene; rth::Settings settings; };
+
+extern "C" {
+rth_scene* rth_scene_new(void) { return new rth_scene(); }
+void rth_scene_free(rth_scene* s) { delete s; }
+void rth_set_asset_dir(const char* dir) { rth::set_asset_dir(dir); }
+int rth_scene_setup(rth_scene* s, const char* name) {
+    if (!s || !name) return RT_ERR_ARG;
+    return s->scene.setup(name) ? RT_OK : RT_ERR_ARG;
+}
+int rth_add_light(rth_scene* s, const float pos[3], float radius, const float color[3]) {
+    rth::Light l; l.pos = rth::Vec3(pos[0], pos[1], pos[2]); l.radius = radius; l.material = rth::Vec3(color[0], color[1], color[2]);
+    s->scene.lights.push_back(l);
+    return RT_OK;
+}
+static rth::Material fromC(const rt_material* m) {
+    rth::Material r;
+    if (!m) return r;
+    r.ambient_material = rth::Vec3(m->ka[0], m->ka[1], m->ka[2]);
+    r.diffuse_material = rth::Vec3(m->kd[0], m->kd[1], m->kd[2]);
+    r.specular_material = rth::Vec3(m->ks[0], m->ks[1], m->ks[2]);
+    r.shininess = m->shininess; r.type = m->type; r.index_medium = m->ior; r.transparency = m->transparency; r.reflectivity = m->reflectivity;
+    return r;
+}
+int rth_add_square(rth_scene* s, const float verts[12], const rt_material* m) {
+    rth::Square q;
+    for (int j = 0; j < 4; j++) q.vertices[j] = rth::Vec3(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]);
+    q.material = fromC(m);
+    s->scene.squares.push_back(q);
+    return RT_OK;
+}
+int rth_add_sphere(rth_scene* s, const float c[3], float radius, const rt_material* m) {
+    rth::Sphere sp; sp.m_center = rth::Vec3(c[0], c[1], c[2]); sp.m_radius = radius; sp.material = fromC(m);
+    s->scene.spheres.push_back(sp);
+    return RT_OK;
+}
+int rth_add_mesh(rth_scene* s, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt, const rt_material* m) {
+    if (nv <= 0 || nt <= 0) return RT_ERR_ARG;
+    for (int64_t i = 0; i < 3 * nt; i++) if (tris[i] >= (uint64_t)nv) return RT_ERR_ARG;
+    s->scene.meshes.emplace_back();
+    rth::Mesh& ms = s->scene.meshes.back();
+    ms.positions.resize((size_t)nv);
+    for (int64_t i = 0; i < nv; i++) ms.positions[i] = rth::Vec3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    ms.triangles.assign(tris, tris + 3 * nt);
+    ms.build_arrays();
+    ms.material = fromC(m);
+    return RT_OK;
+}
+int rth_build(rth_scene* s, int top_depth, int mesh_depth) {
+    if (!s || top_depth < 0 || mesh_depth < 0) return RT_ERR_ARG;
+    if (top_depth > RT_MAX_TOP_DEPTH || mesh_depth > RT_MAX_TREE_DEPTH) return RT_ERR_LIMIT;
+    s->settings.tree_subdivide = (unsigned)mesh_depth;
+    s->scene.applySettings(s->settings);
+    s->scene.topDepthLimit = top_depth;
+    s->scene.buildSceneBvh();
+    s->scene.flatten();
+    return RT_OK;
+}
+const rt_scene_desc* rth_scene_desc(rth_scene* s) { return &s->scene.flatten(); }
+int rth_ray_trace_from_camera(rt_ctx* ctx, rth_scene* s, const rt_camera* cam, const rt_render_params* p, const char* path, double* seconds) {
+    if (!ctx || !s || !cam || !p) return RT_ERR_ARG;
+    rth::Camera c;
+    c.x = cam->x; c.y = cam->y; c.z = cam->z; c._zoom = cam->zoom;
+    for (int i = 0; i < 4; i++) c.curquat[i] = cam->quat[i];
+    c.fovAngle = cam->fovy_deg; c.aspectRatio = cam->aspect; c.nearPlane = cam->znear; c.farPlane = cam->zfar;
+    return rth::ray_trace_from_camera(ctx, s->scene, c, p->img_w, p->img_h, p, path, seconds);
+}
+int rth_write_ppm(const char* path, const float* rgb, int w, int h) { return rth::write_ppm(path, rgb, w, h); }
+int rth_load_off(const char* path, float* verts, int64_t max_v, uint32_t* tris, int64_t max_t, int64_t* nv, int64_t* nt) {
+    rth::Mesh m;
+    if (!m.loadOFF(path)) return RT_ERR_ARG;
+    if (nv) *nv = (int64_t)m.positions.size();
+    if (nt) *nt = (int64_t)m.triangleCount();
+    if (verts) for (int64_t i = 0; i < (int64_t)m.positions.size() && i < max_v; i++) for (int k = 0; k < 3; k++) verts[3 * i + k] = m.positions[i][k];
+    if (tris) for (int64_t i = 0; i < (int64_t)m.triangleCount() && i < max_t; i++) for (int k = 0; k < 3; k++) tris[3 * i + k] = m.triangles[3 * i + k];
+    return RT_OK;
+}
+}

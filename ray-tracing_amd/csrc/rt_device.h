@@ -1,0 +1,199 @@
+/*
+ * rt_device.h -- device-side arithmetic of the render loop for gfx950 (wave64).
+ *
+ * Every function restates one reference routine in IEEE float32 with the
+ * reference's operation order (the translation unit is compiled with
+ * -ffp-contract=off; hipcc's default correctly-rounded f32 divide/sqrt is kept),
+ * so that hit identities and geometry are bit-identical to the CPU path.
+ * Places where the reference promotes to double are double here as well.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#define RT_DEV __device__ __forceinline__
+
+struct F3 { float x, y, z; };
+
+RT_DEV F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV F3 f3s(float s) { return f3(s, s, s); }
+RT_DEV F3 add(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }            /* Vec3.h:97 */
+RT_DEV F3 sub(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }            /* Vec3.h:100 */
+RT_DEV F3 mul(float s, F3 a) { return f3(s * a.x, s * a.y, s * a.z); }               /* Vec3.h:103,106 */
+RT_DEV F3 divs(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }              /* Vec3.h:109 */
+RT_DEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }           /* Vec3.h:38 */
+RT_DEV F3 cross(F3 a, F3 b) {                                                        /* Vec3.h:41 */
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_DEV F3 comp(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }           /* Vec3.h:66 */
+RT_DEV float sqlen(F3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }               /* Vec3.h:29 */
+/* Vec3.h:32 computes sqrt in double and narrows; for a float argument that equals the
+ * correctly rounded float sqrt (53 >= 2*24+2 bits); sqrtf lowers to the correctly rounded
+ * sequence on gfx950 (__fsqrt_rn would be the 1-ulp v_sqrt_f32). */
+RT_DEV float len(F3 a) { return sqrtf(sqlen(a)); }
+RT_DEV F3 normalized(F3 a) { float L = len(a); return f3(a.x / L, a.y / L, a.z / L); }   /* Vec3.h:37 */
+RT_DEV float comp_at(F3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+/* Counter RNG in place of random()/rand() (Scene.h:115-116, main.cpp:195-196). */
+__host__ __device__ inline uint32_t rt_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t rt_rng_impl(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code,
+                                                uint32_t light, uint32_t i, uint32_t which) {
+    uint32_t h = rt_mix32(seed + 0x9e3779b9U);
+    h = rt_mix32((h ^ pixel) + 0x9e3779b9U);
+    h = rt_mix32((h ^ sample) + 0x9e3779b9U);
+    h = rt_mix32((h ^ (uint32_t)code) + 0x9e3779b9U);
+    h = rt_mix32((h ^ (uint32_t)(code >> 32)) + 0x9e3779b9U);
+    h = rt_mix32((h ^ light) + 0x9e3779b9U);
+    h = rt_mix32((h ^ i) + 0x9e3779b9U);
+    h = rt_mix32((h ^ which) + 0x9e3779b9U);
+    return h;
+}
+
+/* ---------------------------------------------------------------- device scene */
+struct DMat {              /* 64 B */
+    float ka[3], kd[3], ks[3];
+    float ior;
+    double shininess;
+    int32_t type;
+    float transparency, reflectivity;
+    int32_t pad;
+};
+struct DLight { float pos[3]; float radius; float color[3]; float pad; };
+struct DMesh { int32_t root; int32_t material; int32_t pad[2]; };
+
+struct DScene {
+    const float4* tri;          /* 4 x float4 per triangle, leaf order: (c0,D) (c1,area) (c2,-) (n,-) */
+    const uint4* tri_ids;       /* (v0, v1, v2 global vertex ids, index into Mesh::triangles), leaf order */
+    const float* normals;       /* 3 per vertex */
+    const float4* mnodes;       /* 4 x float4 per inner node, links made global */
+    const uint2* mleaves;       /* (first, count) into tri, global */
+    const DMesh* meshes;
+    const float4* tnodes;
+    const uint2* tleaves;
+    const uint32_t* titems;
+    const float4* squares;      /* 4 x float4: (bl,D) (right,|right|^2) (up,|up|^2) (n,material) */
+    const float4* spheres;      /* 2 x float4: (center,radius) (material,-,-,-) */
+    const DMat* mats;
+    const DLight* lights;
+    const double* sincos;       /* sin[360], cos[360] of (float)k * degToRad, host libm (Scene.h:112-119) */
+    int32_t n_lights, n_squares, n_spheres, n_meshes;
+    int32_t top_root;
+    int32_t top_cap;            /* stack entries reserved for the top level */
+    int32_t stack_cap;          /* total per-lane stack entries */
+};
+
+struct Ray { F3 o, d, inv; };
+/* Ray/Line constructor (Line.h:13-16): the direction is normalised again. */
+RT_DEV Ray make_ray(F3 o, F3 d) {
+    Ray r;
+    r.o = o;
+    r.d = normalized(d);
+    r.inv = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);   /* AccelerationStruct.cpp:19, hoisted: same value every call */
+    return r;
+}
+
+/* AABB::intersect, AccelerationStruct.cpp:13-30 (tMin = 0, tMax = 100, NaN-ignoring max/min). */
+RT_DEV bool slab(const Ray& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float& tEnter) {
+    float tMin = 0.0f, tMax = 100.0f;
+    {
+        float t0 = (mnx - r.o.x) * r.inv.x, t1 = (mxx - r.o.x) * r.inv.x;
+        if (r.inv.x < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+        tMin = (tMin < t0) ? t0 : tMin;
+        tMax = (t1 < tMax) ? t1 : tMax;
+        if (tMin > tMax) return false;
+    }
+    {
+        float t0 = (mny - r.o.y) * r.inv.y, t1 = (mxy - r.o.y) * r.inv.y;
+        if (r.inv.y < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+        tMin = (tMin < t0) ? t0 : tMin;
+        tMax = (t1 < tMax) ? t1 : tMax;
+        if (tMin > tMax) return false;
+    }
+    {
+        float t0 = (mnz - r.o.z) * r.inv.z, t1 = (mxz - r.o.z) * r.inv.z;
+        if (r.inv.z < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+        tMin = (tMin < t0) ? t0 : tMin;
+        tMax = (t1 < tMax) ? t1 : tMax;
+        if (tMin > tMax) return false;
+    }
+    tEnter = tMin;
+    return true;
+}
+
+/* Triangle::getIntersection (Triangle.h:86-121) on a record precomputed at upload:
+ * c0,c1,c2 already scaled by 1.0001f (Mesh.cpp:107-109), n/area per Triangle.h:28-33,
+ * D = dot(c0,n) per Triangle.h:58. Returns exists; t,w0,w1,w2 out. */
+RT_DEV bool tri_test(const Ray& r, float4 q0, float4 q1, float4 q2, float4 q3, float& t_out, float& w0, float& w1, float& w2) {
+    F3 c0 = f3(q0.x, q0.y, q0.z), c1 = f3(q1.x, q1.y, q1.z), c2 = f3(q2.x, q2.y, q2.z), n = f3(q3.x, q3.y, q3.z);
+    float D = q0.w, area = q1.w;
+    float dn = dot(r.d, n);
+    if (dn == 0) return false;                                   /* Triangle.h:49-53 */
+    float t = (D - dot(r.o, n)) / dn;                            /* Triangle.h:59 */
+    F3 P = add(r.o, mul(t, r.d));                                /* Triangle.h:61 */
+    F3 cd = normalized(sub(P, r.o));                             /* Triangle.h:94-95 */
+    if (dot(cd, r.d) < 0) return false;                          /* Triangle.h:96 */
+    /* Triangle.h:65-84: (|C| / 2.) / area in double, narrowed; equal to the float quotient below */
+    float u0 = (len(cross(sub(c2, c1), sub(P, c1))) * 0.5f) / area;
+    float u1 = (len(cross(sub(c0, c2), sub(P, c2))) * 0.5f) / area;
+    float u2 = (len(cross(sub(c1, c0), sub(P, c0))) * 0.5f) / area;
+    float sum = u0 + u1 + u2;
+    if ((double)sum < 0.9999 || (double)sum > 1.00001) return false;   /* Triangle.h:105 */
+    t_out = len(sub(r.o, P));                                    /* Triangle.h:110 */
+    w0 = u0; w1 = u1; w2 = u2;
+    return true;
+}
+
+/* Sphere::intersect, Sphere.h:86-146. */
+RT_DEV bool sphere_test(const Ray& r, float4 s, float& t_out, F3& n_out) {
+    F3 c = f3(s.x, s.y, s.z);
+    float radius = s.w;
+    F3 oc = sub(r.o, c);
+    float a = dot(r.d, r.d);
+    float b = 2.0f * dot(oc, r.d);
+    float cc = dot(oc, oc) - (radius * radius);
+    float disc = (b * b) - (4.f * a * cc);
+    float t = 0;
+    if (disc > 0) {
+        float sq = sqrtf(disc);
+        float t1 = (-b - sq) / (2.0f * a);
+        float t2 = (-b + sq) / (2.0f * a);
+        if (t1 > 0 && t2 > 0) t = (t2 < t1) ? t2 : t1;
+        else if (t1 > 0) t = t1;
+        else if (t2 > 0) t = t2;
+        else return false;
+    } else if (disc == 0) {
+        t = (float)((double)(-b) / (2. * (double)a));            /* Sphere.h:113 */
+    }
+    if (t != 0.f) {
+        F3 P = add(r.o, mul(t, r.d));
+        F3 n = normalized(sub(P, c));
+        if (dot(r.d, n) > 0.f) return false;                     /* Sphere.h:122 */
+        t_out = t;
+        n_out = n;
+        return true;
+    }
+    return false;
+}
+
+/* Square::intersect, Square.h:62-111, on a record precomputed at upload. */
+RT_DEV bool square_test(const Ray& r, float4 q0, float4 q1, float4 q2, float4 q3, float& t_out, float& u_out, float& v_out) {
+    F3 bl = f3(q0.x, q0.y, q0.z), right = f3(q1.x, q1.y, q1.z), up = f3(q2.x, q2.y, q2.z), n = f3(q3.x, q3.y, q3.z);
+    float dn = dot(r.d, n);
+    if (dn > 0) return false;                                    /* Square.h:74 */
+    float t = (q0.w - dot(r.o, n)) / dn;                         /* Square.h:77-78 */
+    if (t > 0 && !isinf(t)) {
+        F3 P = add(r.o, mul(t, r.d));
+        F3 d = sub(P, bl);
+        float u = dot(d, right) / q1.w;
+        float v = dot(d, up) / q2.w;
+        if (u >= 0 && u <= 1.0f && v >= 0 && v <= 1.0f) {
+            t_out = t; u_out = u; v_out = v;
+            return true;
+        }
+    }
+    return false;
+}

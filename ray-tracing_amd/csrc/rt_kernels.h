@@ -1,0 +1,631 @@
+/*
+ * rt_kernels.h -- traversal, shading and wavefront kernels (gfx950, wave64).
+ *
+ * Data flow of one wavefront iteration (rtgpu.hip drives it):
+ *   k_raygen      primary rays -> path states           main.cpp:191-201, matrixUtilities.h:198-222
+ *   k_closest     closest hit + material dispatch        Scene.h:174-280, AccelerationStruct.cpp:286-337
+ *                 -> child states (mirror/glass), diffuse records, sky radiance
+ *   k_shadow      one lane per (diffuse hit, light, sample): area-light sample + ordered any-hit
+ *                                                        Scene.h:110-134,160-168
+ *   k_shade       Phong + shadow factor, accumulate      Scene.h:90-108,204-222
+ *   k_resolve     pixel_color /= nsamples                main.cpp:219
+ * Per-lane traversal stacks live in LDS (entry k of lane l at s_stack[k*blockDim+l]:
+ * conflict-free, one bank per lane).
+ */
+#pragma once
+#include "rt_device.h"
+
+#define RT_BLOCK 64
+#define RT_FIX_SCALE 68719476736.0   /* 2^36: radiance accumulators are int64 fixed point */
+
+struct PathState {          /* 64 B */
+    float o[3], d[3], thr[3];
+    uint32_t slot;          /* accumulator index */
+    uint32_t pixel;         /* RNG key */
+    uint32_t sample;        /* RNG key */
+    uint64_t code;          /* path code: 1 primary; child = 2*code (+1 for refraction) */
+    int32_t remaining;      /* NRemainingBounces */
+    uint32_t flags;         /* bit0: write prim id */
+};
+struct DiffuseRec {         /* 64 B + code */
+    float P[3], N[3], V[3], thr[3];
+    uint32_t mat;           /* material index | checker override: bit30 set, bit29 = colour (0 black, 1 white) */
+    uint32_t slot, pixel, sample;
+};
+struct Counters {
+    uint32_t n_child, n_diffuse;
+    uint32_t pad[2];
+    unsigned long long rays_primary, rays_secondary, rays_shadow, nonfinite;
+};
+struct TileD { int32_t x0, y0, w, h; unsigned long long first; };
+struct CameraD { double pinv[16], mvinv[16]; float eye[3]; float pad; };
+struct FrameD {
+    int32_t img_w, img_h, spp, max_depth, light_samples, shadow_mode, jitter;
+    uint32_t seed;
+};
+struct HitD { int exists; float t; int obj; int tri; F3 n; F3 pos; float u, v; int mat; };
+
+RT_DEV int lds_index(int k, int stride) { return k * stride; }
+
+/* BVH_Node::intersect + RayTraceMesh::intersect (AccelerationStruct.cpp:255-283, Mesh.cpp:97-123):
+ * all leaves whose box chain is hit, near child first, first minimal t wins (strict <). */
+RT_DEV void mesh_closest(const DScene& sc, int root, const Ray& r, int* stk, int stride, int sp0,
+                         bool& found, float& bestT, uint32_t& bestG, float& bw0, float& bw1, float& bw2) {
+    found = false;
+    bestT = FLT_MAX;
+    bestG = 0; bw0 = bw1 = bw2 = 0.f;
+    int sp = sp0;
+    int link = root;
+    for (;;) {
+        if (link >= 0) {
+            const float4* nd = sc.mnodes + 4 * (size_t)link;
+            float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+            float tL, tR;
+            bool hL = slab(r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
+            bool hR = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
+            int left = __float_as_int(d.x), right = __float_as_int(d.y);
+            if (hL && hR) {
+                if (tL <= tR) { stk[lds_index(sp++, stride)] = right; link = left; }
+                else { stk[lds_index(sp++, stride)] = left; link = right; }
+                continue;
+            }
+            if (hL) { link = left; continue; }
+            if (hR) { link = right; continue; }
+        } else {
+            uint2 lf = sc.mleaves[-1 - link];
+            for (uint32_t i = 0; i < lf.y; i++) {
+                uint32_t g = lf.x + i;
+                const float4* q = sc.tri + 4 * (size_t)g;
+                float t, w0, w1, w2;
+                if (tri_test(r, q[0], q[1], q[2], q[3], t, w0, w1, w2) && t < bestT) {
+                    found = true; bestT = t; bestG = g; bw0 = w0; bw1 = w1; bw2 = w2;
+                }
+            }
+        }
+        if (sp == sp0) break;
+        link = stk[lds_index(--sp, stride)];
+    }
+}
+
+/* Same candidate set, shadow use: returns 2 when some triangle is hit at t <= lightDistance
+ * (the leaf loop of intersectObjects then returns at once, AccelerationStruct.cpp:309),
+ * 1 when the mesh is hit only beyond it, 0 when not at all. */
+RT_DEV int mesh_any(const DScene& sc, int root, const Ray& r, float lightDistance, int* stk, int stride, int sp0) {
+    int sp = sp0;
+    int link = root;
+    int res = 0;
+    for (;;) {
+        if (link >= 0) {
+            const float4* nd = sc.mnodes + 4 * (size_t)link;
+            float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+            float tL, tR;
+            bool hL = slab(r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
+            bool hR = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
+            int left = __float_as_int(d.x), right = __float_as_int(d.y);
+            if (hL && hR) { stk[lds_index(sp++, stride)] = right; link = left; continue; }
+            if (hL) { link = left; continue; }
+            if (hR) { link = right; continue; }
+        } else {
+            uint2 lf = sc.mleaves[-1 - link];
+            for (uint32_t i = 0; i < lf.y; i++) {
+                const float4* q = sc.tri + 4 * (size_t)(lf.x + i);
+                float t, w0, w1, w2;
+                if (tri_test(r, q[0], q[1], q[2], q[3], t, w0, w1, w2)) {
+                    if (t <= lightDistance) return 2;
+                    if (t < FLT_MAX) res = 1;
+                }
+            }
+        }
+        if (sp == sp0) break;
+        link = stk[lds_index(--sp, stride)];
+    }
+    return res;
+}
+
+/* BVH_Node::intersectObjects(ray) with stopAtFirst=false (AccelerationStruct.cpp:286-337):
+ * every hit child is visited, left first; ties keep the earlier result. */
+RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
+    HitD best;
+    best.exists = 0; best.t = FLT_MAX; best.obj = -1; best.tri = 0; best.mat = 0;
+    best.n = f3s(0.f); best.pos = f3s(0.f); best.u = best.v = 0.f;
+    int kind = -1;
+    uint32_t bestG = 0;
+    float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
+    int sp = 0;
+    int link = sc.top_root;
+    for (;;) {
+        if (link >= 0) {
+            const float4* nd = sc.tnodes + 4 * (size_t)link;
+            float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+            float tL, tR;
+            bool hL = slab(r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
+            bool hR = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
+            int left = __float_as_int(d.x), right = __float_as_int(d.y);
+            if (hL && hR) { stk[lds_index(sp++, stride)] = right; link = left; continue; }
+            if (hL) { link = left; continue; }
+            if (hR) { link = right; continue; }
+        } else {
+            uint2 lf = sc.tleaves[-1 - link];
+            for (uint32_t i = 0; i < lf.y; i++) {
+                int ord = (int)sc.titems[lf.x + i];
+                if (ord < sc.n_squares) {
+                    const float4* q = sc.squares + 4 * ord;
+                    float4 q3 = q[3];
+                    float t, u, v;
+                    if (square_test(r, q[0], q[1], q[2], q3, t, u, v) && t < best.t) {
+                        best.exists = 1; best.t = t; best.obj = ord; best.tri = 0; kind = 0;
+                        best.n = f3(q3.x, q3.y, q3.z); best.u = u; best.v = v; best.mat = __float_as_int(q3.w);
+                    }
+                } else if (ord < sc.n_squares + sc.n_spheres) {
+                    const float4* q = sc.spheres + 2 * (ord - sc.n_squares);
+                    float t; F3 n;
+                    if (sphere_test(r, q[0], t, n) && t < best.t) {
+                        best.exists = 1; best.t = t; best.obj = ord; best.tri = 0; kind = 1;
+                        best.n = n; best.u = best.v = 0.f; best.mat = __float_as_int(q[1].x);
+                    }
+                } else {
+                    DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
+                    bool found; float t; uint32_t g; float w0, w1, w2;
+                    mesh_closest(sc, m.root, r, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
+                    if (found && t < best.t) {
+                        best.exists = 1; best.t = t; best.obj = ord; kind = 2;
+                        bestG = g; bw0 = w0; bw1 = w1; bw2 = w2; best.mat = m.material;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        link = stk[lds_index(--sp, stride)];
+    }
+    if (best.exists) {
+        if (kind == 2) {                                         /* Mesh.cpp:117-134 */
+            uint4 id = sc.tri_ids[bestG];
+            const float* nn = sc.normals;
+            F3 n0 = f3(nn[3 * (size_t)id.x], nn[3 * (size_t)id.x + 1], nn[3 * (size_t)id.x + 2]);
+            F3 n1 = f3(nn[3 * (size_t)id.y], nn[3 * (size_t)id.y + 1], nn[3 * (size_t)id.y + 2]);
+            F3 n2 = f3(nn[3 * (size_t)id.z], nn[3 * (size_t)id.z + 1], nn[3 * (size_t)id.z + 2]);
+            best.n = normalized(add(add(mul(bw0, n0), mul(bw1, n1)), mul(bw2, n2)));
+            best.tri = (int)id.w;
+            best.u = bw0; best.v = bw1;
+        }
+        best.pos = add(r.o, mul(best.t, r.d));                   /* Mesh.cpp:131, Sphere.h:136, Square.h:105 */
+    }
+    return best;
+}
+
+/* BVH_Node::intersectObjects(ray, lightDistance, stopAtFirst=true) as Scene::isInShadow uses it
+ * (Scene.h:160-168): leaves in left-first order; the first leaf whose result exists decides --
+ * occluded iff that result has t <= lightDistance, which inside a leaf is reached exactly when
+ * some object of the leaf is hit at t <= lightDistance (AccelerationStruct.cpp:293-311,326-330). */
+RT_DEV bool occluded(const DScene& sc, const Ray& r, float lightDistance, int* stk, int stride) {
+    int sp = 0;
+    int link = sc.top_root;
+    for (;;) {
+        if (link >= 0) {
+            const float4* nd = sc.tnodes + 4 * (size_t)link;
+            float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+            float tL, tR;
+            bool hL = slab(r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
+            bool hR = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
+            int left = __float_as_int(d.x), right = __float_as_int(d.y);
+            if (hL && hR) { stk[lds_index(sp++, stride)] = right; link = left; continue; }
+            if (hL) { link = left; continue; }
+            if (hR) { link = right; continue; }
+        } else {
+            uint2 lf = sc.tleaves[-1 - link];
+            bool leafExists = false;
+            for (uint32_t i = 0; i < lf.y; i++) {
+                int ord = (int)sc.titems[lf.x + i];
+                if (ord < sc.n_squares) {
+                    const float4* q = sc.squares + 4 * ord;
+                    float t, u, v;
+                    if (square_test(r, q[0], q[1], q[2], q[3], t, u, v) && t < FLT_MAX) {
+                        if (t <= lightDistance) return true;
+                        leafExists = true;
+                    }
+                } else if (ord < sc.n_squares + sc.n_spheres) {
+                    const float4* q = sc.spheres + 2 * (ord - sc.n_squares);
+                    float t; F3 n;
+                    if (sphere_test(r, q[0], t, n) && t < FLT_MAX) {
+                        if (t <= lightDistance) return true;
+                        leafExists = true;
+                    }
+                } else {
+                    DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
+                    int res = mesh_any(sc, m.root, r, lightDistance, stk, stride, sc.top_cap);
+                    if (res == 2) return true;
+                    if (res == 1) leafExists = true;
+                }
+            }
+            if (leafExists) return false;
+        }
+        if (sp == 0) break;
+        link = stk[lds_index(--sp, stride)];
+    }
+    return false;
+}
+
+/* Scene::isInShadow, Scene.h:160-168 */
+RT_DEV bool in_shadow(const DScene& sc, F3 P, F3 L, int* stk, int stride) {
+    F3 dir = sub(L, P);
+    float length = len(dir);
+    dir = normalized(dir);
+    Ray r = make_ray(add(P, mul(0.001f, dir)), dir);
+    return occluded(sc, r, length, stk, stride);
+}
+
+/* Material::reflect, Material.h:60-65 */
+RT_DEV F3 reflect_dir(F3 d, F3 n) {
+    F3 md = mul(-1.f, d);
+    F3 parallel = sub(mul(dot(md, n), n), md);
+    return normalized(add(n, parallel));
+}
+
+RT_DEV void store_state(PathState* s, F3 o, F3 d, F3 thr, uint32_t slot, uint32_t pixel, uint32_t sample, uint64_t code,
+                        int remaining, uint32_t flags) {
+    float4* p = reinterpret_cast<float4*>(s);
+    p[0] = make_float4(o.x, o.y, o.z, d.x);
+    p[1] = make_float4(d.y, d.z, thr.x, thr.y);
+    p[2] = make_float4(thr.z, __uint_as_float(slot), __uint_as_float(pixel), __uint_as_float(sample));
+    p[3] = make_float4(__uint_as_float((uint32_t)code), __uint_as_float((uint32_t)(code >> 32)), __int_as_float(remaining),
+                       __uint_as_float(flags));
+}
+
+/* Radiance sums are int64 fixed point (order-independent, so frames are bit-identical for any
+ * tile sharding). The reference lets NaN/Inf pass through its float sums (main.cpp:217-220); here
+ * they are recorded per slot and channel (bit 3k: NaN, 3k+1: +Inf, 3k+2: -Inf) and re-applied by
+ * k_resolve. Finite magnitudes >= 6e7 are treated as infinite. */
+RT_DEV void accumulate(long long* acc, uint32_t* nonfinite, Counters* ctr, uint32_t slot, F3 c) {
+    float v[3] = {c.x, c.y, c.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float x = v[k];
+        if (!(fabsf(x) < 6.0e7f)) {
+            uint32_t bit = (x != x) ? 1u : (x > 0.f ? 2u : 4u);
+            atomicOr(nonfinite + slot, bit << (3 * k));
+            atomicAdd(&ctr->nonfinite, 1ull);
+            continue;
+        }
+        long long q = __double2ll_rn((double)x * RT_FIX_SCALE);
+        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(acc + 3 * (size_t)slot + k), (unsigned long long)q);
+    }
+}
+
+/* wave-aggregated append: every lane of the wave calls this with its own request count */
+RT_DEV uint32_t wave_reserve(uint32_t* counter, uint32_t want) {
+    unsigned long long m1 = __ballot(want == 1), m2 = __ballot(want == 2);
+    int lane = __lane_id();
+    unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t mine = __popcll(m1 & lt) + 2u * __popcll(m2 & lt);
+    uint32_t total = __popcll(m1) + 2u * __popcll(m2);
+    uint32_t base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(counter, total);
+        base = __shfl(base, 0);
+    }
+    return base + mine;
+}
+
+/* ------------------------------------------------------------------ kernels */
+
+/* main.cpp:191-201 + matrixUtilities.h:198-222: one lane per (pixel, sample). */
+RT_DEV void primary_ray(const CameraD& cam, const FrameD& fr, int x, int y, int s, F3& pos, F3& dir) {
+    float ju = 0.5f, jv = 0.5f;
+    uint32_t pixel = (uint32_t)(x + y * fr.img_w);
+    if (fr.jitter) {
+        ju = (float)(rt_rng_impl(fr.seed, pixel, (uint32_t)s, 0, 0xFFFFFFFFu, 0, 0) & 0x7fffffffu) / 2147483648.0f;
+        jv = (float)(rt_rng_impl(fr.seed, pixel, (uint32_t)s, 0, 0xFFFFFFFFu, 0, 1) & 0x7fffffffu) / 2147483648.0f;
+    }
+    float u = ((float)x + ju) / (float)fr.img_w;
+    float v = ((float)y + jv) / (float)fr.img_h;
+    double xn = 2.0 * (double)u - 1.0, yn = -(2.0 * (double)v - 1.0);
+    const double* pi = cam.pinv;
+    double a0 = pi[0] * xn + pi[4] * yn + pi[8] * 0.0 + pi[12] * 1.0;
+    double a1 = pi[1] * xn + pi[5] * yn + pi[9] * 0.0 + pi[13] * 1.0;
+    double a2 = pi[2] * xn + pi[6] * yn + pi[10] * 0.0 + pi[14] * 1.0;
+    double a3 = pi[3] * xn + pi[7] * yn + pi[11] * 0.0 + pi[15] * 1.0;
+    const double* mv = cam.mvinv;
+    double r0 = mv[0] * a0 + mv[4] * a1 + mv[8] * a2 + mv[12] * a3;
+    double r1 = mv[1] * a0 + mv[5] * a1 + mv[9] * a2 + mv[13] * a3;
+    double r2 = mv[2] * a0 + mv[6] * a1 + mv[10] * a2 + mv[14] * a3;
+    double r3 = mv[3] * a0 + mv[7] * a1 + mv[11] * a2 + mv[15] * a3;
+    F3 p = f3((float)(r0 / r3), (float)(r1 / r3), (float)(r2 / r3));
+    pos = f3(cam.eye[0], cam.eye[1], cam.eye[2]);
+    dir = normalized(sub(p, pos));
+}
+
+RT_DEV void locate_sample(const TileD* tiles, int n_tiles, const FrameD& fr, unsigned long long k, int& x, int& y, int& s) {
+    int lo = 0, hi = n_tiles - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (tiles[mid].first <= k) lo = mid; else hi = mid - 1;
+    }
+    TileD t = tiles[lo];
+    unsigned long long local = k - t.first;
+    unsigned long long pix = local / (unsigned)fr.spp;
+    s = (int)(local % (unsigned)fr.spp);
+    x = t.x0 + (int)(pix % (unsigned)t.w);
+    y = t.y0 + (int)(pix / (unsigned)t.w);
+}
+
+__global__ void __launch_bounds__(256) k_raygen(CameraD cam, FrameD fr, const TileD* tiles, int n_tiles, unsigned long long first,
+                                                uint32_t n, PathState* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x, y, s;
+    locate_sample(tiles, n_tiles, fr, first + i, x, y, s);
+    F3 o, d;
+    primary_ray(cam, fr, x, y, s, o, d);
+    uint32_t pixel = (uint32_t)(x + y * fr.img_w);
+    store_state(out + i, o, d, f3s(1.f), pixel, pixel, (uint32_t)s, 1ull, fr.max_depth, s == 0 ? 1u : 0u);
+}
+
+__global__ void __launch_bounds__(256) k_camera_rays(CameraD cam, FrameD fr, int x0, int y0, int w, int h, float* org, float* dir) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = (uint32_t)w * h * fr.spp;
+    if (i >= n) return;
+    uint32_t pix = i / fr.spp;
+    int s = i % fr.spp;
+    F3 o, d;
+    primary_ray(cam, fr, x0 + (int)(pix % w), y0 + (int)(pix / w), s, o, d);
+    org[3 * i] = o.x; org[3 * i + 1] = o.y; org[3 * i + 2] = o.z;
+    dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
+}
+
+/* seeds path states from explicit rays (rt_trace) */
+__global__ void __launch_bounds__(256) k_seed(const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample,
+                                              uint32_t first, uint32_t n, int max_depth, PathState* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t g = first + i;
+    store_state(out + i, f3(org[3 * g], org[3 * g + 1], org[3 * g + 2]), f3(dir[3 * g], dir[3 * g + 1], dir[3 * g + 2]), f3s(1.f), g,
+                pixel[g], sample[g], 1ull, max_depth, 0u);
+}
+
+/* Scene::rayTraceRecursive (Scene.h:174-280) for one path state: the recursion is unrolled into
+ * child states carrying a throughput (radiance is linear in the child radiance, Scene.h:229,263-271). */
+__global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
+                                                      uint32_t child_cap, DiffuseRec* drec, unsigned long long* dcode,
+                                                      uint32_t diffuse_cap, Counters* ctr, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
+    extern __shared__ int s_stack[];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < n;
+    int* stk = s_stack + threadIdx.x;
+    const int stride = blockDim.x;
+
+    uint32_t want_child = 0;
+    bool want_diffuse = false;
+    F3 c_o[2], c_d[2], c_thr[2];
+    uint64_t c_code[2];
+    DiffuseRec rec;
+    uint32_t slot = 0, pixel = 0, sample = 0, flags = 0;
+    uint64_t code = 0;
+    int remaining = 0;
+
+    if (active) {
+        const float4* p = reinterpret_cast<const float4*>(in + i);
+        float4 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+        F3 o = f3(p0.x, p0.y, p0.z), d = f3(p0.w, p1.x, p1.y), thr = f3(p1.z, p1.w, p2.x);
+        slot = __float_as_uint(p2.y); pixel = __float_as_uint(p2.z); sample = __float_as_uint(p2.w);
+        code = (uint64_t)__float_as_uint(p3.x) | ((uint64_t)__float_as_uint(p3.y) << 32);
+        remaining = __float_as_int(p3.z); flags = __float_as_uint(p3.w);
+
+        Ray r = make_ray(o, d);
+        HitD h = closest_hit(sc, r, stk, stride);
+        if ((flags & 1u) && prim) {
+            prim[2 * (size_t)slot] = h.exists ? (uint32_t)h.obj : 0xFFFFFFFFu;
+            prim[2 * (size_t)slot + 1] = h.exists ? (uint32_t)h.tri : 0xFFFFFFFFu;
+        }
+        if (!h.exists) {                                           /* Scene.h:274-278 */
+            float t = (float)(0.5 * ((double)r.d.y + 1.0));
+            float omt = (float)(1.0 - (double)t);
+            F3 sky = add(mul(omt, f3s(1.0f)), mul(t, f3(0.5f, 0.7f, 1.0f)));
+            accumulate(acc, nonfinite, ctr, slot, comp(thr, sky));
+        } else {
+            DMat m = sc.mats[h.mat];
+            uint32_t matword = (uint32_t)h.mat;
+            if (m.type == 3) {                                     /* checker: Material.h:153-161, Scene.h:51,192-197 */
+                const float inv = (float)(1. / 3.f);
+                int xi = (int)floorf(inv * h.pos.x), yi = (int)floorf(inv * h.pos.y), zi = (int)floorf(inv * h.pos.z);
+                bool even = (xi + yi + zi) % 2 == 0;
+                matword |= 0x40000000u | (even ? 0u : 0x20000000u);
+            }
+            if (m.type == 0 || m.type == 3 || remaining <= 0) {   /* Scene.h:204-222: shaded after the shadow pass */
+                want_diffuse = true;
+                F3 V = mul(-1.f, r.d);
+                rec.P[0] = h.pos.x; rec.P[1] = h.pos.y; rec.P[2] = h.pos.z;
+                rec.N[0] = h.n.x; rec.N[1] = h.n.y; rec.N[2] = h.n.z;
+                rec.V[0] = V.x; rec.V[1] = V.y; rec.V[2] = V.z;
+                rec.thr[0] = thr.x; rec.thr[1] = thr.y; rec.thr[2] = thr.z;
+                rec.mat = matword; rec.slot = slot; rec.pixel = pixel; rec.sample = sample;
+            } else if (m.type == 2) {                              /* mirror, Scene.h:225-229 */
+                F3 nd = reflect_dir(r.d, h.n);
+                c_o[0] = add(h.pos, mul(0.001f, h.n));
+                c_d[0] = nd;
+                c_thr[0] = comp(thr, mul(m.reflectivity, f3(m.ks[0], m.ks[1], m.ks[2])));
+                c_code[0] = code * 2;
+                want_child = 1;
+            } else {                                               /* glass, Scene.h:230-272 */
+                float cosTheta = (float)fmin((double)dot(mul(-1.f, r.d), h.n), 1.);
+                float sinTheta = (float)sqrt(1.0 - (double)(cosTheta * cosTheta));
+                bool inside = cosTheta < 0.f;
+                float ri = inside ? m.ior : (float)(1. / (double)m.ior);
+                double r0 = (1 - (double)ri) / (1 + (double)ri);   /* Material.h:79-84 */
+                r0 = r0 * r0;
+                double R = r0 + (1 - r0) * pow((1 - (double)cosTheta), 5.0);
+                F3 kd = f3(m.kd[0], m.kd[1], m.kd[2]);
+                F3 ab = mul(-(h.t * m.transparency), sub(f3s(1.f), kd));   /* Scene.h:267-270 */
+                ab = f3(expf(ab.x), expf(ab.y), expf(ab.z));
+                float fR = (float)R, fT = (float)(1.0 - R);
+                float omtr = (float)(1.0 - (double)m.transparency);
+                /* color = absorb * ((1-tr)*(R*refl + (1-R)*refr) + tr*refr) */
+                c_o[0] = add(h.pos, mul(0.001f, h.n));
+                c_d[0] = reflect_dir(r.d, h.n);
+                c_thr[0] = comp(thr, mul(omtr * fR, ab));
+                c_code[0] = code * 2;
+                want_child = 1;
+                if (!((double)(ri * sinTheta) > 1.0)) {
+                    double off = inside ? 0.00001 : -0.00001;
+                    F3 perp = mul(ri, add(r.d, mul(cosTheta, h.n)));         /* Material.h:67-76 */
+                    float k = (float)(1.0 - (double)sqlen(perp));
+                    if (!(k < 0.0f)) {
+                        F3 para = mul(-sqrtf(k), h.n);
+                        F3 fd = normalized(add(para, perp));
+                        if (sqlen(fd) != 0) {
+                            c_o[1] = add(h.pos, mul((float)off, h.n));
+                            c_d[1] = fd;
+                            c_thr[1] = comp(thr, mul(omtr * fT + m.transparency, ab));
+                            c_code[1] = code * 2 + 1;
+                            want_child = 2;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    /* wave-uniform section: ray statistics and queue appends */
+    {
+        unsigned long long mp = __ballot(active && code == 1ull), ms = __ballot(active && code != 1ull);
+        if (__lane_id() == 0) {
+            if (mp) atomicAdd(&ctr->rays_primary, (unsigned long long)__popcll(mp));
+            if (ms) atomicAdd(&ctr->rays_secondary, (unsigned long long)__popcll(ms));
+        }
+    }
+    uint32_t cbase = wave_reserve(&ctr->n_child, want_child);
+    uint32_t dbase = wave_reserve(&ctr->n_diffuse, want_diffuse ? 1u : 0u);
+    if (want_child && cbase + want_child <= child_cap) {
+        for (uint32_t k = 0; k < want_child; k++)
+            store_state(child + cbase + k, c_o[k], c_d[k], c_thr[k], slot, pixel, sample, c_code[k], remaining - 1, 0u);
+    }
+    if (want_diffuse && dbase < diffuse_cap) {
+        float4* q = reinterpret_cast<float4*>(drec + dbase);
+        q[0] = make_float4(rec.P[0], rec.P[1], rec.P[2], rec.N[0]);
+        q[1] = make_float4(rec.N[1], rec.N[2], rec.V[0], rec.V[1]);
+        q[2] = make_float4(rec.V[2], rec.thr[0], rec.thr[1], rec.thr[2]);
+        q[3] = make_float4(__uint_as_float(rec.mat), __uint_as_float(rec.slot), __uint_as_float(rec.pixel), __uint_as_float(rec.sample));
+        dcode[dbase] = code;
+    }
+}
+
+/* Scene::sampleSphereLight (Scene.h:110-134) with one lane per light sample. Lane index =
+ * (record * n_lights + light) * S + i. cnt[record*n_lights+light] receives the number of
+ * occluded samples (shadowCount). */
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
+                                                     const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
+                                                     uint32_t* cnt, Counters* ctr) {
+    extern __shared__ int s_stack[];
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    bool active = idx < total;
+    int* stk = s_stack + threadIdx.x;
+    const int stride = blockDim.x;
+    uint32_t key = 0xFFFFFFFFu;
+    bool occ = false;
+    if (active) {
+        key = (uint32_t)(idx / (unsigned)S);
+        uint32_t i = (uint32_t)(idx % (unsigned)S);
+        uint32_t rec = key / (uint32_t)sc.n_lights, li = key % (uint32_t)sc.n_lights;
+        const float4* q = reinterpret_cast<const float4*>(drec + rec);
+        float4 q0 = q[0], q3 = q[3];
+        F3 P = f3(q0.x, q0.y, q0.z);
+        DLight L = sc.lights[li];
+        F3 lp = f3(L.pos[0], L.pos[1], L.pos[2]);
+        if (fr.shadow_mode == 0) {
+            uint32_t pixel = __float_as_uint(q3.z), sample = __float_as_uint(q3.w);
+            unsigned long long code = dcode[rec];
+            uint32_t ky = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 0) % 360u;   /* randY first, Scene.h:115 */
+            uint32_t kx = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 1) % 360u;
+            double sinY = sc.sincos[ky], cosY = sc.sincos[360 + ky];
+            double sinX = sc.sincos[kx], cosX = sc.sincos[360 + kx];
+            float p1 = (float)(-sinY), p2 = (float)cosY;                                 /* Scene.h:119 */
+            float p0 = (float)(-sinX * (double)p2);                                      /* Scene.h:121 */
+            p2 = (float)(cosX * (double)p2);                                             /* Scene.h:122 */
+            lp = add(lp, mul(L.radius, f3(p0, p1, p2)));                                 /* Scene.h:124-126 */
+        }
+        occ = in_shadow(sc, P, lp, stk, stride);
+    }
+    /* per-(record,light) reduction inside the wave, then one atomic per segment */
+    unsigned long long am = __ballot(active);
+    if (__lane_id() == 0 && am) atomicAdd(&ctr->rays_shadow, (unsigned long long)__popcll(am));
+    unsigned long long todo = am;
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        uint32_t k0 = __shfl(key, leader);
+        unsigned long long same = __ballot(active && key == k0);
+        unsigned long long hit = __ballot(active && key == k0 && occ);
+        if (__lane_id() == leader && hit) atomicAdd(cnt + k0, (uint32_t)__popcll(hit));
+        todo &= ~same;
+    }
+}
+
+/* Scene::phong (Scene.h:90-108) + the shadow factor of Scene.h:210-222. */
+__global__ void __launch_bounds__(256) k_shade(DScene sc, const DiffuseRec* __restrict__ drec, uint32_t n_rec, int S,
+                                               const uint32_t* __restrict__ cnt, long long* acc, uint32_t* nonfinite, Counters* ctr) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const float4* q = reinterpret_cast<const float4*>(drec + i);
+    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    F3 P = f3(q0.x, q0.y, q0.z), N = f3(q0.w, q1.x, q1.y), V = f3(q1.z, q1.w, q2.x), thr = f3(q2.y, q2.z, q2.w);
+    uint32_t matword = __float_as_uint(q3.x), slot = __float_as_uint(q3.y);
+    DMat m = sc.mats[matword & 0x00FFFFFFu];
+    F3 ka = f3(m.ka[0], m.ka[1], m.ka[2]), kd = f3(m.kd[0], m.kd[1], m.kd[2]), ks = f3(m.ks[0], m.ks[1], m.ks[2]);
+    if (matword & 0x40000000u) { float c = (matword & 0x20000000u) ? 1.f : 0.f; kd = f3s(c); ks = f3s(c); }
+    F3 color = f3s(0.f);
+    float avg = 0.f;
+    for (int li = 0; li < sc.n_lights; li++) {
+        DLight L = sc.lights[li];
+        float strength = (float)cnt[(size_t)i * sc.n_lights + li] / (float)S;            /* Scene.h:133 */
+        avg += strength;
+        F3 Li = f3(L.color[0], L.color[1], L.color[2]);
+        F3 Ld = normalized(sub(f3(L.pos[0], L.pos[1], L.pos[2]), P));
+        float theta = dot(N, Ld);
+        F3 ambient = comp(Li, ka);
+        F3 diffuse = mul((theta < 0.f) ? 0.f : theta, comp(Li, kd));
+        F3 rr = sub(mul((float)(2. * (double)theta), N), Ld);
+        float rv = dot(rr, V);
+        float rDotV = (0.0f < rv) ? rv : 0.0f;
+        F3 specular = mul((float)pow((double)rDotV, m.shininess), comp(Li, ks));
+        color = add(color, add(add(ambient, diffuse), specular));
+    }
+    float f = (float)(1. - (double)(avg / (float)sc.n_lights));
+    color = mul(f, color);
+    accumulate(acc, nonfinite, ctr, slot, comp(thr, color));
+}
+
+__global__ void __launch_bounds__(256) k_resolve(const long long* acc, const uint32_t* nonfinite, uint32_t n_pix, int spp, float* rgb) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix * 3) return;
+    float sum = (float)((double)acc[i] * (1.0 / RT_FIX_SCALE));
+    uint32_t f = (nonfinite[i / 3] >> (3 * (i % 3))) & 7u;
+    if (f) {
+        if ((f & 1u) || (f & 6u) == 6u) sum = __int_as_float(0x7fc00000);
+        else sum = (f & 2u) ? __int_as_float(0x7f800000) : __int_as_float(0xff800000);
+    }
+    rgb[i] = sum / (float)spp;                                                           /* main.cpp:219 */
+}
+
+/* Scene::computeIntersection on explicit rays (rt_intersect). */
+struct HitOut { int32_t exists, obj, tri; float t; float pos[3]; float nrm[3]; float u, v; };
+__global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene sc, const float* org, const float* dir, uint32_t n, HitOut* out) {
+    extern __shared__ int s_stack[];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r = make_ray(f3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), f3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+    HitD h = closest_hit(sc, r, s_stack + threadIdx.x, blockDim.x);
+    HitOut o;
+    o.exists = h.exists; o.obj = h.exists ? h.obj : -1; o.tri = h.exists ? h.tri : 0; o.t = h.exists ? h.t : FLT_MAX;
+    o.pos[0] = h.pos.x; o.pos[1] = h.pos.y; o.pos[2] = h.pos.z;
+    o.nrm[0] = h.n.x; o.nrm[1] = h.n.y; o.nrm[2] = h.n.z;
+    o.u = h.u; o.v = h.v;
+    out[i] = o;
+}
+/* Scene::isInShadow on explicit (point, light) pairs (rt_occluded). */
+__global__ void __launch_bounds__(RT_BLOCK) k_occluded(DScene sc, const float* pts, const float* lp, uint32_t n, int32_t* out) {
+    extern __shared__ int s_stack[];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool o = in_shadow(sc, f3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), f3(lp[3 * i], lp[3 * i + 1], lp[3 * i + 2]),
+                       s_stack + threadIdx.x, blockDim.x);
+    out[i] = o ? 1 : 0;
+}

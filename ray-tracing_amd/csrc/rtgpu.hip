@@ -1,0 +1,791 @@
+/*
+ * rtgpu.hip -- C-ABI of the MI355X render loop (see include/rtgpu.h) and the host
+ * driver of the wavefront path-state loop that replaces Scene::rayTraceRecursive's
+ * recursion and the per-pixel ThreadPool (main.cpp:203-226, Scene.h:174-286).
+ *
+ * Memory layout in HBM (uploaded once by rt_upload_scene):
+ *   tri      4 x float4 per triangle in BVH leaf order (vertices pre-scaled by 1.0001f,
+ *            unit normal, area, plane D precomputed exactly as Triangle.h:28-33,58)
+ *   tri_ids  uint4 per triangle (3 global vertex ids, index into Mesh::triangles)
+ *   normals  3 floats per vertex
+ *   mnodes   64-byte inner nodes of all mesh trees, child links global
+ *   mleaves  (first,count) ranges into tri
+ *   tnodes / tleaves / titems   top-level tree over object ordinals
+ *   squares (64 B), spheres (32 B), materials (64 B), lights (32 B), sin/cos table
+ * Per frame: int64 fixed-point accumulators (3 per pixel), prim ids, a LIFO stack of
+ * 64-byte path states, child/diffuse queues for one batch.
+ */
+#include "rtgpu.h"
+#include "rt_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool has_scene = false, has_camera = false, has_frame = false;
+
+    DScene sc{};
+    std::vector<DevBuf> scene_bufs;
+    int n_lights = 0;
+    CameraD cam{};
+    FrameD fr{};
+    std::vector<TileD> tiles;
+    unsigned long long queued_samples = 0;
+
+    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf;
+    uint32_t batch = 1u << 20;
+    bool debug = false;
+    size_t stack_cap = 0;       /* states */
+    Counters* h_ctr = nullptr;  /* pinned */
+    rt_stats stats{};
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t ev_frame_a = nullptr, ev_frame_b = nullptr;
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(c, RT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(rt_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return RT_OK;
+    if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { b.p = nullptr; return fail(c, RT_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    b.bytes = bytes;
+    return RT_OK;
+}
+void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+
+template <class T>
+int upload(rt_ctx* c, const std::vector<T>& v, const T** out) {
+    DevBuf b;
+    int rc = ensure(c, b, std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(c, hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    c->scene_bufs.push_back(b);
+    *out = static_cast<const T*>(b.p);
+    return RT_OK;
+}
+
+/* host float helpers in the reference's operation order (this file is built with -ffp-contract=off) */
+struct H3 { float x, y, z; };
+inline H3 hsub(H3 a, H3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 hcross(H3 a, H3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float hdot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float hlen(H3 a) { return (float)std::sqrt((double)(a.x * a.x + a.y * a.y + a.z * a.z)); }
+
+/* 4x4 double helpers, column-major as the GL matrices read back by glGetDoublev */
+void m4_identity(double* m) { for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+void m4_mul(const double* a, const double* b, double* o) {
+    double t[16];
+    for (int col = 0; col < 4; col++)
+        for (int row = 0; row < 4; row++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += a[k * 4 + row] * b[col * 4 + k];
+            t[col * 4 + row] = s;
+        }
+    memcpy(o, t, sizeof(t));
+}
+/* gluInvertMatrix (matrixUtilities.h:7-135): adjugate by cofactors. With M[r][c] = m[4r+c],
+ * inv[4b+a] is the cofactor of element (a,b), expanded along the first remaining
+ * column; products are taken left to right and the six terms summed left to right, which is
+ * the evaluation order the reference's explicit expressions have. */
+bool m4_inverse(const double* m, double* out) {
+    double inv[16];
+    for (int a = 0; a < 4; a++)          /* deleted row */
+        for (int b = 0; b < 4; b++) {    /* deleted column */
+            int R[3], C[3], nr = 0, nc = 0;
+            for (int k = 0; k < 4; k++) { if (k != a) R[nr++] = k; if (k != b) C[nc++] = k; }
+            double sgn = ((a + b) & 1) ? -1.0 : 1.0;
+            double sum = 0.0;
+            for (int k = 0; k < 3; k++) {
+                int rA = R[k == 0 ? 1 : 0], rB = R[k == 2 ? 1 : 2];
+                double first = m[4 * R[k] + C[0]];
+                double s = (k == 0) ? sgn : -sgn * (k == 1 ? 1.0 : -1.0);
+                double t1 = (s * first) * m[4 * rA + C[1]] * m[4 * rB + C[2]];
+                double t2 = (-s * first) * m[4 * rA + C[2]] * m[4 * rB + C[1]];
+                if (k == 0) sum = t1 + t2; else sum = sum + t1 + t2;
+            }
+            inv[4 * b + a] = sum;
+        }
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0) return false;
+    det = 1.0 / det;
+    for (int i = 0; i < 16; i++) out[i] = inv[i] * det;
+    return true;
+}
+
+size_t lds_bytes(const rt_ctx* c, int block) { return (size_t)c->sc.stack_cap * block * sizeof(int); }
+
+EventPair* next_event(rt_ctx* c, int kind) {
+    if (c->ev_used == c->ev_pool.size()) {
+        EventPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(p);
+    }
+    EventPair* e = &c->ev_pool[c->ev_used++];
+    e->kind = kind;
+    return e;
+}
+
+struct Source {                 /* where fresh path states come from */
+    bool from_tiles;
+    unsigned long long total;
+    const float* d_org; const float* d_dir; const uint32_t* d_pixel; const uint32_t* d_sample;   /* explicit rays */
+    int max_depth;
+};
+
+/* The wavefront loop. Path states sit on a LIFO stack; every iteration tops the batch up with
+ * fresh primaries, pops up to `batch` states (deepest first, which bounds the live set by
+ * batch*(max_depth+2)), runs closest-hit + material dispatch, the shadow pass and the Phong
+ * pass for that batch, then pushes the children. */
+int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
+    const uint32_t B = c->batch;
+    const int L = c->n_lights;
+    const int S = c->fr.shadow_mode == 1 ? 1 : c->fr.light_samples;
+    size_t need_stack = (size_t)B * (size_t)(src.max_depth + 3);
+    int rc;
+    if ((rc = ensure(c, c->stack, need_stack * sizeof(PathState)))) return rc;
+    c->stack_cap = c->stack.bytes / sizeof(PathState);
+    if ((rc = ensure(c, c->child, (size_t)2 * B * sizeof(PathState)))) return rc;
+    if ((rc = ensure(c, c->drec, (size_t)B * sizeof(DiffuseRec)))) return rc;
+    if ((rc = ensure(c, c->dcode, (size_t)B * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(c, c->cnt, (size_t)B * std::max(L, 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->ctr, sizeof(Counters)))) return rc;
+    if (!c->h_ctr) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
+    if (src.from_tiles) {
+        if ((rc = ensure(c, c->tilebuf, std::max<size_t>(c->tiles.size(), 1) * sizeof(TileD)))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->tilebuf.p, c->tiles.data(), c->tiles.size() * sizeof(TileD), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(Counters), c->stream));
+
+    PathState* stack = static_cast<PathState*>(c->stack.p);
+    Counters* d_ctr = static_cast<Counters*>(c->ctr.p);
+    size_t top = 0;
+    unsigned long long done = 0;
+    size_t lds = lds_bytes(c, RT_BLOCK);
+    c->ev_used = 0;
+
+    while (done < src.total || top > 0) {
+        /* 1. top up with fresh primaries */
+        uint32_t room = top < B ? (uint32_t)(B - top) : 0u;
+        uint32_t n_new = (uint32_t)std::min<unsigned long long>(src.total - done, room);
+        if (n_new) {
+            dim3 g((n_new + 255) / 256), b(256);
+            if (src.from_tiles)
+                hipLaunchKernelGGL(k_raygen, g, b, 0, c->stream, c->cam, c->fr, static_cast<const TileD*>(c->tilebuf.p), (int)c->tiles.size(),
+                                   done, n_new, stack + top);
+            else
+                hipLaunchKernelGGL(k_seed, g, b, 0, c->stream, src.d_org, src.d_dir, src.d_pixel, src.d_sample, (uint32_t)done, n_new,
+                                   src.max_depth, stack + top);
+            top += n_new;
+            done += n_new;
+        }
+        /* 2. pop the batch */
+        uint32_t nb = (uint32_t)std::min<size_t>(top, B);
+        size_t base = top - nb;
+        top = base;
+        HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, 16, c->stream));    /* n_child, n_diffuse */
+        EventPair* e1 = next_event(c, 0);
+        if (!e1) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+        HIP_TRY(c, hipEventRecord(e1->a, c->stream));
+        hipLaunchKernelGGL(k_closest, dim3((nb + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, c->stream, c->sc, stack + base, nb,
+                           static_cast<PathState*>(c->child.p), 2 * B, static_cast<DiffuseRec*>(c->drec.p),
+                           static_cast<unsigned long long*>(c->dcode.p), B, d_ctr, acc, nonfinite, prim);
+        HIP_TRY(c, hipEventRecord(e1->b, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        uint32_t n_child = c->h_ctr->n_child, n_diff = c->h_ctr->n_diffuse;
+        if (c->debug) fprintf(stderr, "[rtgpu] iter %llu: new %u batch %u -> children %u diffuse %u (stack %zu)\n",
+                              (unsigned long long)c->stats.iterations, n_new, nb, n_child, n_diff, top);
+        if (n_child > 2 * B || n_diff > B) return fail(c, RT_ERR_LIMIT, "queue overflow (%u children, %u diffuse)", n_child, n_diff);
+        /* 3. shadow + Phong for the diffuse records of this batch */
+        if (n_diff && L > 0) {
+            HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
+            unsigned long long threads = (unsigned long long)n_diff * L * S;
+            unsigned long long blocks = (threads + RT_BLOCK - 1) / RT_BLOCK;
+            if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "shadow grid too large");
+            EventPair* e2 = next_event(c, 1);
+            if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+            HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+            hipLaunchKernelGGL(k_shadow, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds, c->stream, c->sc, c->fr,
+                               static_cast<const DiffuseRec*>(c->drec.p), static_cast<const unsigned long long*>(c->dcode.p), n_diff, S,
+                               static_cast<uint32_t*>(c->cnt.p), d_ctr);
+            HIP_TRY(c, hipEventRecord(e2->b, c->stream));
+        }
+        if (n_diff) {
+            if (L == 0) HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, 256, c->stream));
+            hipLaunchKernelGGL(k_shade, dim3((n_diff + 255) / 256), dim3(256), 0, c->stream, c->sc, static_cast<const DiffuseRec*>(c->drec.p),
+                               n_diff, S, static_cast<const uint32_t*>(c->cnt.p), acc, nonfinite, d_ctr);
+        }
+        /* 4. push the children */
+        if (n_child) {
+            if (top + n_child > c->stack_cap) return fail(c, RT_ERR_LIMIT, "path-state stack overflow");
+            HIP_TRY(c, hipMemcpyAsync(stack + top, c->child.p, (size_t)n_child * sizeof(PathState), hipMemcpyDeviceToDevice, c->stream));
+            top += n_child;
+        }
+        c->stats.iterations++;
+        c->stats.peak_states = std::max<uint64_t>(c->stats.peak_states, top);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    c->stats.rays_primary += c->h_ctr->rays_primary;
+    c->stats.rays_secondary += c->h_ctr->rays_secondary;
+    c->stats.rays_shadow += c->h_ctr->rays_shadow;
+    c->stats.nonfinite += c->h_ctr->nonfinite;
+    for (size_t i = 0; i < c->ev_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) {
+            if (c->ev_pool[i].kind == 0) { c->stats.ms_closest += ms; c->stats.launches_closest++; }
+            else { c->stats.ms_shadow += ms; c->stats.launches_shadow++; }
+        }
+    }
+    return RT_OK;
+}
+
+int check_desc(rt_ctx* c, const rt_scene_desc* d) {
+    if (d->n_lights > RT_MAX_LIGHTS) return fail(c, RT_ERR_LIMIT, "more than %d lights", RT_MAX_LIGHTS);
+    if (d->n_materials <= 0 && (d->n_squares + d->n_spheres + d->n_meshes) > 0) return fail(c, RT_ERR_ARG, "no materials");
+    if (d->top_depth > RT_MAX_TOP_DEPTH) return fail(c, RT_ERR_LIMIT, "top-level tree deeper than %d", RT_MAX_TOP_DEPTH);
+    int n_obj = d->n_squares + d->n_spheres + d->n_meshes;
+    auto link_ok = [](int32_t link, int64_t n_nodes, int64_t n_leaves) {
+        return link >= 0 ? (int64_t)link < n_nodes : (int64_t)(-1 - link) < n_leaves;
+    };
+    if (n_obj > 0 && !link_ok(d->top_root, d->n_top_nodes, d->n_top_leaves)) return fail(c, RT_ERR_ARG, "top_root out of range");
+    for (int i = 0; i < d->n_top_nodes; i++)
+        if (!link_ok(d->top_nodes[i].left, d->n_top_nodes, d->n_top_leaves) || !link_ok(d->top_nodes[i].right, d->n_top_nodes, d->n_top_leaves))
+            return fail(c, RT_ERR_ARG, "top node %d: child link out of range", i);
+    for (int i = 0; i < d->n_top_leaves; i++)
+        if ((int64_t)d->top_leaves[i].first + d->top_leaves[i].count > d->n_top_items) return fail(c, RT_ERR_ARG, "top leaf %d out of range", i);
+    for (int i = 0; i < d->n_top_items; i++)
+        if ((int)d->top_items[i] >= n_obj) return fail(c, RT_ERR_ARG, "top item %d: object ordinal out of range", i);
+    for (int i = 0; i < d->n_squares; i++) if (d->squares[i].material < 0 || d->squares[i].material >= d->n_materials) return fail(c, RT_ERR_ARG, "square material");
+    for (int i = 0; i < d->n_spheres; i++) if (d->spheres[i].material < 0 || d->spheres[i].material >= d->n_materials) return fail(c, RT_ERR_ARG, "sphere material");
+    for (int mi = 0; mi < d->n_meshes; mi++) {
+        const rt_mesh& m = d->meshes[mi];
+        if (m.material < 0 || m.material >= d->n_materials) return fail(c, RT_ERR_ARG, "mesh material");
+        if (m.depth > RT_MAX_TREE_DEPTH) return fail(c, RT_ERR_LIMIT, "mesh %d: tree deeper than %d", mi, RT_MAX_TREE_DEPTH);
+        if (m.vert_first < 0 || m.vert_first + m.vert_count > d->n_verts || m.tri_first < 0 || m.tri_first + m.tri_count > d->n_tris ||
+            m.node_first < 0 || m.node_first + m.node_count > d->n_mesh_nodes || m.leaf_first < 0 || m.leaf_first + m.leaf_count > d->n_mesh_leaves)
+            return fail(c, RT_ERR_ARG, "mesh %d: range out of bounds", mi);
+        if (m.tri_count <= 0 || !link_ok(m.root, m.node_count, m.leaf_count)) return fail(c, RT_ERR_ARG, "mesh %d: bad root", mi);
+        for (int64_t i = 0; i < m.node_count; i++) {
+            const rt_bvh_node& n = d->mesh_nodes[m.node_first + i];
+            if (!link_ok(n.left, m.node_count, m.leaf_count) || !link_ok(n.right, m.node_count, m.leaf_count))
+                return fail(c, RT_ERR_ARG, "mesh %d node %lld: child link out of range", mi, (long long)i);
+        }
+        for (int64_t i = 0; i < m.leaf_count; i++) {
+            const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + i];
+            if ((int64_t)lf.first + lf.count > m.tri_count) return fail(c, RT_ERR_ARG, "mesh %d leaf %lld out of range", mi, (long long)i);
+        }
+        for (int64_t i = 0; i < m.tri_count; i++) {
+            if (d->mesh_items[m.tri_first + i] >= (uint64_t)m.tri_count) return fail(c, RT_ERR_ARG, "mesh %d: item out of range", mi);
+            for (int k = 0; k < 3; k++)
+                if (d->tri_indices[3 * (m.tri_first + i) + k] >= (uint64_t)m.vert_count) return fail(c, RT_ERR_ARG, "mesh %d: vertex index out of range", mi);
+        }
+    }
+    if (d->n_tris > 0x7FFFFFF0ll || d->n_mesh_nodes > 0x7FFFFFF0ll || d->n_mesh_leaves > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "scene too large for 32-bit links");
+    return RT_OK;
+}
+
+void free_scene(rt_ctx* c) {
+    for (DevBuf& b : c->scene_bufs) release(b);
+    c->scene_bufs.clear();
+    c->has_scene = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code, uint32_t light, uint32_t i, uint32_t which) {
+    return rt_rng_impl(seed, pixel, sample, code, light, i, which);
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
+    if (!out) return RT_ERR_ARG;
+    *out = nullptr;
+    if (n_devices != 1) return RT_ERR_ARG;      /* one process per GPU */
+    int dev = device_ids ? device_ids[0] : 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || dev < 0 || dev >= count) return RT_ERR_DEVICE;
+    rt_ctx* c = new rt_ctx();
+    c->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev_frame_a) != hipSuccess ||
+        hipEventCreate(&c->ev_frame_b) != hipSuccess) {
+        delete c;
+        return RT_ERR_DEVICE;
+    }
+    const char* b = getenv("RT_BATCH");
+    if (b && atoi(b) >= 1024) c->batch = (uint32_t)atoi(b);
+    c->debug = getenv("RT_DEBUG") != nullptr;
+    *out = c;
+    return RT_OK;
+}
+
+void rt_shutdown(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf}) release(*b);
+    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    for (EventPair& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    (void)hipEventDestroy(c->ev_frame_a);
+    (void)hipEventDestroy(c->ev_frame_b);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
+    if (!c || !d) return RT_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = check_desc(c, d);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    DScene sc{};
+
+    /* triangles in leaf order with the per-test quantities of Triangle.h precomputed */
+    std::vector<float4> tri((size_t)d->n_tris * 4);
+    std::vector<uint4> ids((size_t)d->n_tris);
+    std::vector<rt_bvh_node> nodes(d->mesh_nodes, d->mesh_nodes + d->n_mesh_nodes);
+    std::vector<uint2> leaves((size_t)d->n_mesh_leaves);
+    std::vector<DMesh> meshes((size_t)d->n_meshes);
+    int max_mesh_depth = 0;
+    for (int mi = 0; mi < d->n_meshes; mi++) {
+        const rt_mesh& m = d->meshes[mi];
+        max_mesh_depth = std::max(max_mesh_depth, m.depth);
+        for (int64_t j = 0; j < m.tri_count; j++) {
+            uint32_t t = d->mesh_items[m.tri_first + j];
+            const uint32_t* iv = d->tri_indices + 3 * (m.tri_first + t);
+            H3 c0, c1, c2;
+            {
+                const float* p0 = d->positions + 3 * (m.vert_first + iv[0]);
+                const float* p1 = d->positions + 3 * (m.vert_first + iv[1]);
+                const float* p2 = d->positions + 3 * (m.vert_first + iv[2]);
+                const float s = 1.0001f;                           /* Mesh.cpp:107-109 */
+                c0 = {s * p0[0], s * p0[1], s * p0[2]};
+                c1 = {s * p1[0], s * p1[1], s * p1[2]};
+                c2 = {s * p2[0], s * p2[1], s * p2[2]};
+            }
+            H3 nn = hcross(hsub(c1, c0), hsub(c2, c0));            /* Triangle.h:28-33 */
+            float norm = hlen(nn);
+            H3 n = {nn.x / norm, nn.y / norm, nn.z / norm};
+            float area = norm / 2.f;
+            float D = hdot(c0, n);                                 /* Triangle.h:58 */
+            size_t g = (size_t)(m.tri_first + j);
+            tri[4 * g + 0] = make_float4(c0.x, c0.y, c0.z, D);
+            tri[4 * g + 1] = make_float4(c1.x, c1.y, c1.z, area);
+            tri[4 * g + 2] = make_float4(c2.x, c2.y, c2.z, 0.f);
+            tri[4 * g + 3] = make_float4(n.x, n.y, n.z, 0.f);
+            ids[g] = make_uint4((uint32_t)(m.vert_first + iv[0]), (uint32_t)(m.vert_first + iv[1]), (uint32_t)(m.vert_first + iv[2]), t);
+        }
+        auto glob = [&](int32_t link) { return link >= 0 ? (int32_t)(link + m.node_first) : (int32_t)(-1 - ((-1 - link) + m.leaf_first)); };
+        for (int64_t i = 0; i < m.node_count; i++) {
+            rt_bvh_node& n = nodes[(size_t)(m.node_first + i)];
+            n.left = glob(n.left);
+            n.right = glob(n.right);
+        }
+        for (int64_t i = 0; i < m.leaf_count; i++) {
+            const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + i];
+            leaves[(size_t)(m.leaf_first + i)] = make_uint2((uint32_t)(lf.first + m.tri_first), lf.count);
+        }
+        meshes[mi].root = glob(m.root);
+        meshes[mi].material = m.material;
+    }
+    if (d->n_verts > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "too many vertices");
+    std::vector<float> normals(d->normals, d->normals + 3 * d->n_verts);
+
+    std::vector<float4> squares((size_t)d->n_squares * 4);
+    for (int i = 0; i < d->n_squares; i++) {                       /* Square.h:67-71,77,85-86 */
+        const rt_square& s = d->squares[i];
+        H3 bl = {s.v0[0], s.v0[1], s.v0[2]};
+        H3 right = hsub({s.v1[0], s.v1[1], s.v1[2]}, bl), up = hsub({s.v3[0], s.v3[1], s.v3[2]}, bl);
+        H3 nn = hcross(right, up);
+        float L = hlen(nn);
+        H3 n = {nn.x / L, nn.y / L, nn.z / L};
+        float D = hdot(bl, n);
+        float rs = right.x * right.x + right.y * right.y + right.z * right.z;
+        float us = up.x * up.x + up.y * up.y + up.z * up.z;
+        float mf;
+        memcpy(&mf, &s.material, 4);
+        squares[4 * i + 0] = make_float4(bl.x, bl.y, bl.z, D);
+        squares[4 * i + 1] = make_float4(right.x, right.y, right.z, rs);
+        squares[4 * i + 2] = make_float4(up.x, up.y, up.z, us);
+        squares[4 * i + 3] = make_float4(n.x, n.y, n.z, mf);
+    }
+    std::vector<float4> spheres((size_t)d->n_spheres * 2);
+    for (int i = 0; i < d->n_spheres; i++) {
+        const rt_sphere& s = d->spheres[i];
+        float mf;
+        memcpy(&mf, &s.material, 4);
+        spheres[2 * i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius);
+        spheres[2 * i + 1] = make_float4(mf, 0.f, 0.f, 0.f);
+    }
+    std::vector<DMat> mats((size_t)d->n_materials);
+    for (int i = 0; i < d->n_materials; i++) {
+        const rt_material& m = d->materials[i];
+        DMat& o = mats[i];
+        memset(&o, 0, sizeof(o));
+        for (int k = 0; k < 3; k++) { o.ka[k] = m.ka[k]; o.kd[k] = m.kd[k]; o.ks[k] = m.ks[k]; }
+        o.ior = m.ior; o.shininess = m.shininess; o.type = m.type; o.transparency = m.transparency; o.reflectivity = m.reflectivity;
+    }
+    std::vector<DLight> lights((size_t)d->n_lights);
+    for (int i = 0; i < d->n_lights; i++) {
+        memset(&lights[i], 0, sizeof(DLight));
+        for (int k = 0; k < 3; k++) { lights[i].pos[k] = d->lights[i].pos[k]; lights[i].color[k] = d->lights[i].color[k]; }
+        lights[i].radius = d->lights[i].radius;
+    }
+    /* sin/cos of the 360 integer-degree angles, evaluated by the host libm exactly where the
+     * reference evaluates them (Scene.h:112-122: float angle, double sin/cos) */
+    std::vector<double> sincos(720);
+    {
+        float degToRad = (float)(M_PI / 180.);
+        for (int k = 0; k < 360; k++) {
+            float ang = (float)(long)k * degToRad;
+            sincos[k] = std::sin((double)ang);
+            sincos[360 + k] = std::cos((double)ang);
+        }
+    }
+    std::vector<rt_bvh_node> tnodes(d->top_nodes, d->top_nodes + d->n_top_nodes);
+    std::vector<uint2> tleaves((size_t)d->n_top_leaves);
+    for (int i = 0; i < d->n_top_leaves; i++) tleaves[i] = make_uint2(d->top_leaves[i].first, d->top_leaves[i].count);
+    std::vector<uint32_t> titems(d->top_items, d->top_items + d->n_top_items);
+
+    const rt_bvh_node* dn = nullptr;
+    const rt_bvh_node* dtn = nullptr;
+    if ((rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
+        (rc = upload(c, nodes, &dn)) || (rc = upload(c, leaves, &sc.mleaves)) || (rc = upload(c, meshes, &sc.meshes)) ||
+        (rc = upload(c, tnodes, &dtn)) || (rc = upload(c, tleaves, &sc.tleaves)) || (rc = upload(c, titems, &sc.titems)) ||
+        (rc = upload(c, squares, &sc.squares)) || (rc = upload(c, spheres, &sc.spheres)) || (rc = upload(c, mats, &sc.mats)) ||
+        (rc = upload(c, lights, &sc.lights)) || (rc = upload(c, sincos, &sc.sincos))) {
+        free_scene(c);
+        return rc;
+    }
+    sc.mnodes = reinterpret_cast<const float4*>(dn);
+    sc.tnodes = reinterpret_cast<const float4*>(dtn);
+    sc.n_lights = d->n_lights; sc.n_squares = d->n_squares; sc.n_spheres = d->n_spheres; sc.n_meshes = d->n_meshes;
+    sc.top_root = (d->n_squares + d->n_spheres + d->n_meshes) > 0 ? d->top_root : -1;
+    if ((d->n_squares + d->n_spheres + d->n_meshes) == 0) {
+        /* empty scene: a single empty leaf */
+        std::vector<uint2> one(1, make_uint2(0, 0));
+        if ((rc = upload(c, one, &sc.tleaves))) { free_scene(c); return rc; }
+    }
+    sc.top_cap = d->top_depth + 2;
+    sc.stack_cap = sc.top_cap + max_mesh_depth + 2;
+    c->sc = sc;
+    c->n_lights = d->n_lights;
+    c->has_scene = true;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx* c, const rt_camera* cam) {
+    if (!c || !cam) return RT_ERR_ARG;
+    /* Camera::apply (Camera.cpp:125-132): I * T(x,y,z) * T(0,0,-zoom) * R, all glMultMatrix calls */
+    double mv[16], t[16], r[16];
+    m4_identity(mv);
+    m4_identity(t); t[12] = cam->x; t[13] = cam->y; t[14] = cam->z;
+    m4_mul(mv, t, mv);
+    m4_identity(t); t[14] = -(double)cam->zoom;
+    m4_mul(mv, t, mv);
+    {   /* build_rotmatrix, Trackball.cpp:323-345; the float[4][4] is read by glMultMatrixf as column-major */
+        const float* q = cam->quat;
+        float m[16];
+        m[0] = (float)(1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]));
+        m[1] = (float)(2.0 * (q[0] * q[1] - q[2] * q[3]));
+        m[2] = (float)(2.0 * (q[2] * q[0] + q[1] * q[3]));
+        m[3] = 0.0f;
+        m[4] = (float)(2.0 * (q[0] * q[1] + q[2] * q[3]));
+        m[5] = (float)(1.0 - 2.0 * (q[2] * q[2] + q[0] * q[0]));
+        m[6] = (float)(2.0 * (q[1] * q[2] - q[0] * q[3]));
+        m[7] = 0.0f;
+        m[8] = (float)(2.0 * (q[2] * q[0] - q[1] * q[3]));
+        m[9] = (float)(2.0 * (q[1] * q[2] + q[0] * q[3]));
+        m[10] = (float)(1.0 - 2.0 * (q[1] * q[1] + q[0] * q[0]));
+        m[11] = 0.0f;
+        m[12] = 0.0f; m[13] = 0.0f; m[14] = 0.0f; m[15] = 1.0f;
+        for (int i = 0; i < 16; i++) r[i] = m[i];
+    }
+    m4_mul(mv, r, mv);
+    /* gluPerspective(fovAngle, aspectRatio, nearPlane, farPlane), Camera.cpp:48 */
+    double p[16];
+    memset(p, 0, sizeof(p));
+    double radians = (double)cam->fovy_deg / 2.0 * M_PI / 180.0;
+    double sine = std::sin(radians);
+    double deltaZ = (double)cam->zfar - (double)cam->znear;
+    if (deltaZ == 0.0 || sine == 0.0 || cam->aspect == 0.0f) return fail(c, RT_ERR_ARG, "degenerate projection");
+    double cot = std::cos(radians) / sine;
+    p[0] = cot / (double)cam->aspect;
+    p[5] = cot;
+    p[10] = -((double)cam->zfar + (double)cam->znear) / deltaZ;
+    p[11] = -1.0;
+    p[14] = -2.0 * (double)cam->znear * (double)cam->zfar / deltaZ;
+    if (!m4_inverse(p, c->cam.pinv) || !m4_inverse(mv, c->cam.mvinv)) return fail(c, RT_ERR_ARG, "singular camera matrix");
+    /* cameraSpaceToWorldSpace(0,0,0), matrixUtilities.h:188-197 */
+    const double* mi = c->cam.mvinv;
+    double w = mi[15];
+    c->cam.eye[0] = (float)(mi[12] / w);
+    c->cam.eye[1] = (float)(mi[13] / w);
+    c->cam.eye[2] = (float)(mi[14] / w);
+    c->has_camera = true;
+    return RT_OK;
+}
+
+static int check_params(rt_ctx* c, const rt_render_params* p) {
+    if (p->img_w <= 0 || p->img_h <= 0 || (int64_t)p->img_w * p->img_h > 0x3FFFFFFFll) return fail(c, RT_ERR_ARG, "bad image size");
+    if (p->spp <= 0 || p->spp > 65535) return fail(c, RT_ERR_ARG, "spp out of range");
+    if (p->max_depth < 0 || p->max_depth > RT_MAX_PATH_DEPTH) return fail(c, RT_ERR_LIMIT, "max_depth above %d", RT_MAX_PATH_DEPTH);
+    if (p->light_samples <= 0 || p->light_samples > 4096) return fail(c, RT_ERR_ARG, "light_samples out of range");
+    if (p->shadow_mode < 0 || p->shadow_mode > 1) return fail(c, RT_ERR_ARG, "shadow_mode");
+    return RT_OK;
+}
+static void set_frame(rt_ctx* c, const rt_render_params* p) {
+    c->fr.img_w = p->img_w; c->fr.img_h = p->img_h; c->fr.spp = p->spp; c->fr.max_depth = p->max_depth;
+    c->fr.light_samples = p->light_samples; c->fr.shadow_mode = p->shadow_mode; c->fr.jitter = p->jitter; c->fr.seed = p->seed;
+}
+
+int rt_begin_frame(rt_ctx* c, const rt_render_params* p) {
+    if (!c || !p) return RT_ERR_ARG;
+    if (!c->has_scene) return fail(c, RT_ERR_STATE, "rt_begin_frame before rt_upload_scene");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    set_frame(c, p);
+    size_t npix = (size_t)p->img_w * p->img_h;
+    if ((rc = ensure(c, c->acc, npix * 3 * sizeof(long long)))) return rc;
+    if ((rc = ensure(c, c->prim, npix * 2 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->nf, npix * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->rgb, npix * 3 * sizeof(float)))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->acc.p, 0, npix * 3 * sizeof(long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->prim.p, 0xFF, npix * 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->nf.p, 0, npix * sizeof(uint32_t), c->stream));
+    c->tiles.clear();
+    c->queued_samples = 0;
+    memset(&c->stats, 0, sizeof(c->stats));
+    c->has_frame = true;
+    return RT_OK;
+}
+
+int rt_render_tile(rt_ctx* c, int x0, int y0, int w, int h) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_render_tile before rt_begin_frame");
+    if (!c->has_camera) return fail(c, RT_ERR_STATE, "rt_render_tile before rt_set_camera");
+    if (w < 0 || h < 0 || x0 < 0 || y0 < 0 || x0 + w > c->fr.img_w || y0 + h > c->fr.img_h) return fail(c, RT_ERR_ARG, "tile outside the image");
+    if (w == 0 || h == 0) return RT_OK;
+    TileD t;
+    t.x0 = x0; t.y0 = y0; t.w = w; t.h = h; t.first = c->queued_samples;
+    c->tiles.push_back(t);
+    c->queued_samples += (unsigned long long)w * h * c->fr.spp;
+    return RT_OK;
+}
+
+int rt_flush(rt_ctx* c) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_flush before rt_begin_frame");
+    if (c->tiles.empty()) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    Source src{};
+    src.from_tiles = true;
+    src.total = c->queued_samples;
+    src.max_depth = c->fr.max_depth;
+    HIP_TRY(c, hipEventRecord(c->ev_frame_a, c->stream));
+    int rc = run_wavefront(c, src, static_cast<long long*>(c->acc.p), static_cast<uint32_t*>(c->nf.p), static_cast<uint32_t*>(c->prim.p));
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_frame_b, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev_frame_b));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_frame_a, c->ev_frame_b));
+    c->stats.ms_total += ms;
+    c->tiles.clear();
+    c->queued_samples = 0;
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx* c, rt_stats* s) {
+    if (!c || !s) return RT_ERR_ARG;
+    *s = c->stats;
+    return RT_OK;
+}
+
+int rt_resolve_device(rt_ctx* c, void* d_rgb) {
+    if (!c || !d_rgb) return RT_ERR_ARG;
+    int rc = rt_flush(c);
+    if (rc) return rc;
+    uint32_t npix = (uint32_t)((size_t)c->fr.img_w * c->fr.img_h);
+    hipLaunchKernelGGL(k_resolve, dim3((npix * 3 + 255) / 256), dim3(256), 0, c->stream, static_cast<const long long*>(c->acc.p),
+                       static_cast<const uint32_t*>(c->nf.p), npix, c->fr.spp, static_cast<float*>(d_rgb));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_download_framebuffer(rt_ctx* c, float* rgb, uint32_t* prim_id, rt_stats* stats) {
+    if (!c || !rgb) return RT_ERR_ARG;
+    int rc = rt_resolve_device(c, c->rgb.p);
+    if (rc) return rc;
+    size_t npix = (size_t)c->fr.img_w * c->fr.img_h;
+    HIP_TRY(c, hipMemcpy(rgb, c->rgb.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (prim_id) HIP_TRY(c, hipMemcpy(prim_id, c->prim.p, npix * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (stats) *stats = c->stats;
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ fine-grained seams */
+static int stage_in(rt_ctx* c, DevBuf& b, const void* host, size_t bytes) {
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(b.p, host, bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_intersect(rt_ctx* c, const float* org, const float* dir, int64_t n, rt_hit* out) {
+    if (!c || !org || !dir || !out || n < 0 || n > 0x7FFFFFFFll) return RT_ERR_ARG;
+    if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    static_assert(sizeof(HitOut) == sizeof(rt_hit), "hit layout");
+    DevBuf a, b, o;
+    int rc;
+    if ((rc = stage_in(c, a, org, (size_t)n * 12)) || (rc = stage_in(c, b, dir, (size_t)n * 12)) || (rc = ensure(c, o, (size_t)n * sizeof(HitOut)))) {
+        release(a); release(b); release(o);
+        return rc;
+    }
+    hipLaunchKernelGGL(k_intersect, dim3(((uint32_t)n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds_bytes(c, RT_BLOCK), c->stream, c->sc,
+                       static_cast<const float*>(a.p), static_cast<const float*>(b.p), (uint32_t)n, static_cast<HitOut*>(o.p));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, o.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost);
+    release(a); release(b); release(o);
+    if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, "rt_intersect: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_occluded(rt_ctx* c, const float* pts, const float* lp, int64_t n, int32_t* out) {
+    if (!c || !pts || !lp || !out || n < 0 || n > 0x7FFFFFFFll) return RT_ERR_ARG;
+    if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf a, b, o;
+    int rc;
+    if ((rc = stage_in(c, a, pts, (size_t)n * 12)) || (rc = stage_in(c, b, lp, (size_t)n * 12)) || (rc = ensure(c, o, (size_t)n * 4))) {
+        release(a); release(b); release(o);
+        return rc;
+    }
+    hipLaunchKernelGGL(k_occluded, dim3(((uint32_t)n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds_bytes(c, RT_BLOCK), c->stream, c->sc,
+                       static_cast<const float*>(a.p), static_cast<const float*>(b.p), (uint32_t)n, static_cast<int32_t*>(o.p));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, o.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+    release(a); release(b); release(o);
+    if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, "rt_occluded: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_trace(rt_ctx* c, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample, int64_t n,
+             const rt_render_params* p, float* rgb) {
+    if (!c || !org || !dir || !pixel || !sample || !p || !rgb || n < 0 || n > 0x3FFFFFFFll) return RT_ERR_ARG;
+    if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
+    if (n == 0) return RT_OK;
+    rt_render_params q = *p;
+    if (q.img_w <= 0) q.img_w = 1;
+    if (q.img_h <= 0) q.img_h = 1;
+    q.spp = 1;
+    int rc = check_params(c, &q);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    FrameD saved = c->fr;
+    rt_stats saved_stats = c->stats;
+    set_frame(c, &q);
+    DevBuf a, b, px, sm, acc, nf, out;
+    auto cleanup = [&]() { release(a); release(b); release(px); release(sm); release(acc); release(nf); release(out); c->fr = saved; c->stats = saved_stats; };
+    if ((rc = stage_in(c, a, org, (size_t)n * 12)) || (rc = stage_in(c, b, dir, (size_t)n * 12)) || (rc = stage_in(c, px, pixel, (size_t)n * 4)) ||
+        (rc = stage_in(c, sm, sample, (size_t)n * 4)) || (rc = ensure(c, acc, (size_t)n * 3 * sizeof(long long))) ||
+        (rc = ensure(c, nf, (size_t)n * sizeof(uint32_t))) || (rc = ensure(c, out, (size_t)n * 3 * sizeof(float)))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(acc.p, 0, (size_t)n * 3 * sizeof(long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(nf.p, 0, (size_t)n * sizeof(uint32_t), c->stream);
+    if (e != hipSuccess) { cleanup(); return fail(c, RT_ERR_DEVICE, "memset: %s", hipGetErrorString(e)); }
+    Source src{};
+    src.from_tiles = false;
+    src.total = (unsigned long long)n;
+    src.d_org = static_cast<const float*>(a.p); src.d_dir = static_cast<const float*>(b.p);
+    src.d_pixel = static_cast<const uint32_t*>(px.p); src.d_sample = static_cast<const uint32_t*>(sm.p);
+    src.max_depth = q.max_depth;
+    rc = run_wavefront(c, src, static_cast<long long*>(acc.p), static_cast<uint32_t*>(nf.p), nullptr);
+    if (rc == RT_OK) {
+        hipLaunchKernelGGL(k_resolve, dim3(((uint32_t)n * 3 + 255) / 256), dim3(256), 0, c->stream, static_cast<const long long*>(acc.p),
+                           static_cast<const uint32_t*>(nf.p), (uint32_t)n, 1, static_cast<float*>(out.p));
+        e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(rgb, out.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, RT_ERR_DEVICE, "rt_trace: %s", hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+int rt_camera_rays(rt_ctx* c, const rt_render_params* p, int x0, int y0, int w, int h, float* org, float* dir) {
+    if (!c || !p || !org || !dir || w <= 0 || h <= 0) return RT_ERR_ARG;
+    if (!c->has_camera) return fail(c, RT_ERR_STATE, "no camera");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    size_t n = (size_t)w * h * p->spp;
+    if (n > 0x3FFFFFFFull) return fail(c, RT_ERR_LIMIT, "too many rays");
+    HIP_TRY(c, hipSetDevice(c->device));
+    FrameD fr;
+    fr.img_w = p->img_w; fr.img_h = p->img_h; fr.spp = p->spp; fr.max_depth = p->max_depth; fr.light_samples = p->light_samples;
+    fr.shadow_mode = p->shadow_mode; fr.jitter = p->jitter; fr.seed = p->seed;
+    DevBuf a, b;
+    if ((rc = ensure(c, a, n * 12)) || (rc = ensure(c, b, n * 12))) { release(a); release(b); return rc; }
+    hipLaunchKernelGGL(k_camera_rays, dim3(((uint32_t)n + 255) / 256), dim3(256), 0, c->stream, c->cam, fr, x0, y0, w, h, static_cast<float*>(a.p),
+                       static_cast<float*>(b.p));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(org, a.p, n * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(dir, b.p, n * 12, hipMemcpyDeviceToHost);
+    release(a); release(b);
+    if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, "rt_camera_rays: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"

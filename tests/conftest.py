@@ -1,0 +1,28 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rt():
+    """The product package (ctypes over librtgpu.so)."""
+    return importlib.import_module("ray-tracing_amd")
+
+
+@pytest.fixture(scope="session")
+def ctx(rt):
+    """One GPU context for the whole session (GPU tests only)."""
+    c = rt.Context(0)
+    yield c
+    c.close()

@@ -1,0 +1,268 @@
+"""GPU parity: the HIP path through the C-ABI against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): hit identities (object ordinal, triangle index) exact -- and here
+also t / position / normal bit-exact; radiance max |delta| <= 1/255 on the 8-bit output
+(PSNR >= 50 dB for stochastic soft-shadow configs).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import psnr
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["final", "refraction", "reflexion", "mesh_gorilla", "mesh_cow", "soup:20000"]
+_cache = {}
+
+
+def scene_pair(rt, ctx, name, mesh_depth=12):
+    key = (name, mesh_depth)
+    if key not in _cache:
+        _cache[key] = (rt.HostScene(name, 3, mesh_depth), O.Scene(name, 3, mesh_depth))
+    hs, os_ = _cache[key]
+    ctx.upload_scene(hs)
+    return hs, os_
+
+
+def cams(rt, aspect=1.0):
+    near = (rt.default_camera(aspect), O.default_camera(aspect))
+    far = (rt.default_camera(aspect, zoom=25.0), O.default_camera(aspect, zoom=25.0))
+    return [near, far]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_hits_equal(g, o, what):
+    assert np.array_equal(g["exists"], o["exists"]), f"{what}: exists differs at {np.flatnonzero(g['exists'] != o['exists'])[:8]}"
+    assert np.array_equal(g["obj"], o["obj"]), f"{what}: object ids differ at {np.flatnonzero(g['obj'] != o['obj'])[:8]}"
+    assert np.array_equal(g["tri"], o["tri"]), f"{what}: triangle ids differ at {np.flatnonzero(g['tri'] != o['tri'])[:8]}"
+    m = o["exists"] == 1
+    for f in ("t", "pos", "nrm", "u", "v"):
+        assert np.array_equal(bits(g[f][m]), bits(o[f][m])), f"{what}: field {f} not bit-exact"
+
+
+@pytest.mark.parametrize("jitter", [0, 1])
+def test_camera_rays_bit_exact(rt, ctx, jitter):
+    for aspect, quat in ((1.0, (0, 0, 0, 1)), (16 / 9, (0.1, -0.2, 0.05, 0.97))):
+        gc, oc = rt.default_camera(aspect), O.default_camera(aspect)
+        q = np.array(quat, np.float32)
+        q /= np.linalg.norm(q)
+        gc.quat[:] = q.tolist()
+        oc.quat[:] = q.tolist()
+        ctx.set_camera(gc)
+        gp = rt.make_params(64, 36, spp=3, jitter=jitter, seed=7)
+        op = O.make_params(64, 36, spp=3, jitter=jitter, seed=7)
+        go, gd = ctx.camera_rays(gp, 5, 3, 40, 20)
+        oo, od = O.camera_rays(oc, op, 5, 3, 40, 20)
+        assert np.array_equal(bits(go), bits(oo))
+        assert np.array_equal(bits(gd), bits(od))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_primary_hits_exact(rt, ctx, name):
+    hs, os_ = scene_pair(rt, ctx, name)
+    for gc, oc in cams(rt):
+        op = O.make_params(96, 96, spp=1)
+        org, dirs = O.camera_rays(oc, op, 0, 0, 96, 96)
+        assert_hits_equal(ctx.intersect(org, dirs), os_.intersect(org, dirs), f"{name} zoom {oc.zoom}")
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_random_and_axis_rays_exact(rt, ctx, name):
+    hs, os_ = scene_pair(rt, ctx, name)
+    rng = np.random.default_rng(1234)
+    n = 6000
+    org = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
+    org[:, 1] = rng.uniform(-1.9, 6, n)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    # adversarial: axis-aligned directions (1/0 = inf in the slab test), unnormalised, tiny components
+    dirs[:600] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 600)] * rng.choice([-1, 1], (600, 1)).astype(np.float32)
+    dirs[600:900, 0] = 0.0
+    dirs[900:1200] *= 1e-3
+    dirs[1200:1500, 1] *= 1e-6
+    assert_hits_equal(ctx.intersect(org, dirs), os_.intersect(org, dirs), name)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_shadow_queries_exact(rt, ctx, name):
+    hs, os_ = scene_pair(rt, ctx, name)
+    gc, oc = cams(rt)[1]
+    org, dirs = O.camera_rays(oc, O.make_params(64, 64, spp=1), 0, 0, 64, 64)
+    h = os_.intersect(org, dirs)
+    pts = h["pos"][h["exists"] == 1]
+    if len(pts) == 0:
+        pytest.skip("no hits")
+    rng = np.random.default_rng(5)
+    nl = os_.counts()[3]
+    lights = np.stack([os_.light(i % nl)[0] for i in range(len(pts))]).astype(np.float32)
+    lights2 = lights + rng.normal(scale=3.0, size=lights.shape).astype(np.float32)
+    for lp in (lights, lights2):
+        g = ctx.occluded(pts, lp)
+        o = os_.shadow(pts, lp)
+        assert np.array_equal(g, o), f"{name}: {np.count_nonzero(g != o)} of {len(o)} shadow results differ"
+    assert 0 < o.sum() or name in ("refraction", "reflexion"), "test should see some occlusion"
+
+
+def radiance_check(g, o, what, tol_q=1):
+    # NaN radiance (e.g. NaN vertex normals next to a degenerate triangle) passes through both paths
+    assert np.array_equal(np.isnan(g), np.isnan(o)), f"{what}: NaN pixels differ"
+    g, o = np.nan_to_num(g, nan=0.0), np.nan_to_num(o, nan=0.0)
+    qg, qo = O.quantize(g), O.quantize(o)
+    dq = np.abs(qg - qo)
+    rel = np.abs(g - o) / (1e-3 + np.abs(o))
+    assert dq.max() <= tol_q, f"{what}: 8-bit output differs by {dq.max()} levels at {np.argwhere(dq > tol_q)[:4]}"
+    return float(rel.max())
+
+
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("shadow_mode", [1, 0])
+def test_ray_trace_radiance(rt, ctx, name, shadow_mode):
+    """Scene::rayTrace per ray (depth 50, 35 light samples): tolerance 1/255 on the 8-bit value."""
+    hs, os_ = scene_pair(rt, ctx, name)
+    res = 40 if name == "final" else 64
+    for gc, oc in cams(rt):
+        # the pulled-back view of the default scene sees the glass gorilla: at depth 50 one pixel owns
+        # millions of rays, minutes for the single-threaded oracle -> depth 7 there
+        depth = 7 if (name == "final" and oc.zoom > 3.0) else 50
+        op = O.make_params(res, res, spp=1, shadow_mode=shadow_mode, seed=3, max_depth=depth)
+        gp = rt.make_params(res, res, spp=1, shadow_mode=shadow_mode, jitter=0, seed=3, max_depth=depth)
+        org, dirs = O.camera_rays(oc, op, 0, 0, res, res)
+        pix = np.arange(len(org), dtype=np.uint32)
+        g = ctx.trace(org, dirs, gp, pix)
+        o = os_.trace(org, dirs, op, pix)
+        # float tolerance written out: |delta| <= 1/255 after min(1, .) quantisation (north_star)
+        rel = radiance_check(g, o, f"{name} mode {shadow_mode} zoom {oc.zoom}")
+        assert np.allclose(np.minimum(g, 4.0), np.minimum(o, 4.0), atol=1.0 / 255.0)
+        assert rel < 0.05
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth", [("final", 64, 64, 2, 50), ("refraction", 160, 90, 4, 5),
+                                                 ("mesh_gorilla", 128, 72, 2, 50), ("soup:20000", 96, 54, 4, 5)])
+def test_render_frame(rt, ctx, name, w, h, spp, depth):
+    hs, os_ = scene_pair(rt, ctx, name)
+    aspect = w / h
+    gc, oc = rt.default_camera(aspect), O.default_camera(aspect)
+    gp = rt.make_params(w, h, spp=spp, max_depth=depth, jitter=1, seed=11)
+    op = O.make_params(w, h, spp=spp, max_depth=depth, jitter=1, seed=11)
+    rgb, prim, st = ctx.render(gc, gp)
+    orgb, oprim, ost, _ = os_.render(oc, op, threads=8)
+    oprim_u = oprim.astype(np.int64)
+    oprim_u[oprim[..., 0] < 0] = 0xFFFFFFFF
+    assert np.array_equal(prim.astype(np.int64), oprim_u), "primary-hit primitive ids differ"
+    assert (st.rays_primary, st.rays_secondary) == (ost.rays_primary, ost.rays_secondary)
+    assert st.rays_shadow == ost.rays_shadow
+    radiance_check(rgb, orgb, name)
+    assert psnr(rgb, orgb) >= 50.0
+    assert st.nonfinite == 0
+
+
+def test_tile_sharding_bit_identical(rt, ctx):
+    """1 GPU vs the union of the interleaved tile sets of 2 and 4 ranks: same bits."""
+    hs, os_ = scene_pair(rt, ctx, "final")
+    cam = rt.default_camera(1.0, zoom=25.0)
+    p = rt.make_params(96, 96, spp=2, seed=5, max_depth=8)
+    full, fprim, _ = ctx.render(cam, p)
+    for world in (2, 4):
+        acc = np.zeros_like(full)
+        aprim = np.full_like(fprim, 0xFFFFFFFF)
+        for rank in range(world):
+            rgb, prim, _ = ctx.render(cam, p, tiles=rt.interleaved_tiles(96, 96, rank, world))
+            acc += rgb
+            aprim = np.minimum(aprim, prim)
+        assert np.array_equal(bits(acc), bits(full))
+        assert np.array_equal(aprim, fprim)
+    again, _, _ = ctx.render(cam, p)
+    assert np.array_equal(bits(again), bits(full)), "run-to-run determinism"
+
+
+def test_small_batches_same_frame(rt, ctx, monkeypatch):
+    """A tiny wavefront batch (many iterations, deep LIFO stack) gives the same frame."""
+    hs, os_ = scene_pair(rt, ctx, "final")
+    cam = rt.default_camera(1.0)
+    p = rt.make_params(48, 48, spp=2, seed=1)
+    full, fprim, st = ctx.render(cam, p)
+    monkeypatch.setenv("RT_BATCH", "1024")
+    c2 = rt.Context(0)
+    try:
+        c2.upload_scene(hs)
+        rgb, prim, st2 = c2.render(cam, p)
+    finally:
+        c2.close()
+    assert np.array_equal(bits(rgb), bits(full)) and np.array_equal(prim, fprim)
+    assert st2.iterations > st.iterations
+    assert st2.rays == st.rays
+
+
+def test_drop_in_entry_point_writes_ppm(rt, ctx, tmp_path):
+    hs, os_ = scene_pair(rt, ctx, "reflexion")
+    gc, oc = rt.default_camera(1.0), O.default_camera(1.0)
+    gp = rt.make_params(80, 80, spp=2, seed=2)
+    path = str(tmp_path / "rendu.ppm")
+    ctx.ray_trace_from_camera(hs, gc, gp, path)
+    tok = open(path).read().split()
+    assert tok[:4] == ["P3", "80", "80", "255"]
+    img = np.array(tok[4:], np.int32).reshape(80, 80, 3)
+    orgb, _, _, _ = os_.render(oc, O.make_params(80, 80, spp=2, jitter=1, seed=2), threads=8)
+    assert np.abs(img - O.quantize(orgb)).max() <= 1
+
+
+def test_free_form_scene_and_edge_cases(rt, ctx):
+    """Empty scene, single-triangle mesh (root leaf), degenerate triangle, light inside geometry."""
+    hs, os_ = rt.HostScene(), O.Scene()
+    hs.build(3, 12)
+    os_.build(3, 12)
+    ctx.upload_scene(hs)
+    org = np.zeros((4, 3), np.float32)
+    dirs = np.array([[0, 0, -1], [0, 1, 0], [1, 0, 0], [0, -1, 0]], np.float32)
+    assert ctx.intersect(org, dirs)["exists"].sum() == 0
+    p = rt.make_params(1, 1, spp=1, jitter=0)
+    assert np.array_equal(bits(ctx.trace(org, dirs, p)), bits(os_.trace(org, dirs, O.make_params(1, 1, spp=1))))
+
+    hs, os_ = rt.HostScene(), O.Scene()
+    tri_v = np.array([[-1, -1, -3], [1, -1, -3], [0, 1, -3]], np.float32)
+    deg_v = np.array([[0, 0, -2], [0, 0, -2], [1, 1, -2], [2, 0, -2.5]], np.float32)
+    for s, M in ((hs, rt), (os_, O)):
+        mat = M.Material()
+        mat.kd[:] = [0.8, 0.2, 0.2]
+        mat.ks[:] = [0.5, 0.5, 0.5]
+        mat.shininess = 8.0
+        s.add_light([0.2, 0.3, 2.0], 0.25)
+        s.add_mesh(tri_v, np.array([[0, 1, 2]], np.uint32), mat)
+        s.add_mesh(deg_v, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), mat)
+        s.add_sphere([0.0, 0.0, -1.0], 0.5, mat)
+        s.build(3, 12)
+    ctx.upload_scene(hs)
+    oc = O.default_camera(1.0, zoom=0.0, z=-1.5)
+    org, dirs = O.camera_rays(oc, O.make_params(48, 48, spp=1), 0, 0, 48, 48)
+    assert_hits_equal(ctx.intersect(org, dirs), os_.intersect(org, dirs), "free-form")
+    g = ctx.trace(org, dirs, rt.make_params(48, 48, spp=1, jitter=0))
+    o = os_.trace(org, dirs, O.make_params(48, 48, spp=1))
+    radiance_check(g, o, "free-form")
+    assert np.isnan(o).any(), "the degenerate triangle should poison some normals"
+
+
+def test_call_order_and_limits(rt):
+    c = rt.Context(0)
+    try:
+        with pytest.raises(rt.RtError):
+            c.begin_frame(rt.make_params(8, 8))          # no scene
+        hs = rt.HostScene("reflexion")
+        c.upload_scene(hs)
+        with pytest.raises(rt.RtError):
+            c.render_tile(0, 0, 8, 8)                    # no frame
+        c.begin_frame(rt.make_params(8, 8))
+        with pytest.raises(rt.RtError):
+            c.render_tile(0, 0, 8, 8)                    # no camera
+        c.set_camera(rt.default_camera())
+        with pytest.raises(rt.RtError):
+            c.render_tile(4, 4, 8, 8)                    # outside the image
+        with pytest.raises(rt.RtError):
+            c.begin_frame(rt.make_params(8, 8, max_depth=1000))
+        c.render_tile(0, 0, 0, 0)                        # empty tile is a no-op
+        rgb, prim, st = c.download()
+        assert st.rays == 0 and not rgb.any()
+    finally:
+        c.close()
