@@ -63,7 +63,7 @@ struct DMat {              /* 64 B */
     int32_t pad;
 };
 struct DLight { float pos[3]; float radius; float color[3]; float pad; };
-struct DMesh { int32_t root; int32_t material; int32_t pad[2]; };
+struct DMesh { int32_t root; int32_t material; float delta; int32_t pad; };   /* delta: see prune_slack() */
 
 struct DScene {
     const float4* tri;          /* 4 x float4 per triangle, leaf order: (c0,D) (c1,area) (c2,-) (n,-) */

@@ -36,6 +36,8 @@ struct Counters {
     uint32_t n_child, n_diffuse;
     uint32_t pad[2];
     unsigned long long rays_primary, rays_secondary, rays_shadow, nonfinite;
+    unsigned long long work;        /* next unclaimed shadow-ray index of the running k_shadow launch */
+    unsigned long long pad2;
 };
 struct TileD { int32_t x0, y0, w, h; unsigned long long first; };
 struct CameraD { double pinv[16], mvinv[16]; float eye[3]; float pad; };
@@ -47,15 +49,33 @@ struct HitD { int exists; float t; int obj; int tri; F3 n; F3 pos; float u, v; i
 
 RT_DEV int lds_index(int k, int stride) { return k * stride; }
 
+/* Result-preserving pruning. A triangle record is the mesh triangle scaled by 1.0001f about the
+ * origin (Mesh.cpp:107-109) and accepted with a barycentric tolerance (Triangle.h:105), so its hit
+ * point can lie up to ~1e-4*|coordinate| outside the (unscaled) box of its leaf. DMesh::delta
+ * (8e-4 * largest |coordinate| of the mesh) bounds that with margin; moving a box face by delta moves
+ * a slab entry time by at most delta*max|1/d|, hence every hit below a child has
+ *     t >= (tEnter - delta*max|1/d|) * (1 - 1e-5).
+ * A child whose bound exceeds the distance of interest cannot change the reference's answer (it
+ * would lose the strict `<` of Mesh.cpp:114 or lie beyond the light), so it is skipped. The
+ * reference's own slab test still decides which children are entered and in which order. */
+RT_DEV float prune_slack(const Ray& r, float delta) {
+    float m = fmaxf(fabsf(r.inv.x), fmaxf(fabsf(r.inv.y), fabsf(r.inv.z)));
+    return delta * m;    /* inf for axis-parallel rays: nothing is pruned */
+}
+RT_DEV bool beyond(float tEnter, float slack, float bound) { return (tEnter - slack) * 0.99999f > bound; }
+
 /* BVH_Node::intersect + RayTraceMesh::intersect (AccelerationStruct.cpp:255-283, Mesh.cpp:97-123):
- * all leaves whose box chain is hit, near child first, first minimal t wins (strict <). */
-RT_DEV void mesh_closest(const DScene& sc, int root, const Ray& r, int* stk, int stride, int sp0,
+ * all leaves whose box chain is hit, near child first, first minimal t wins (strict <).
+ * `bound` = the best t found so far in the leaf loop of intersectObjects: a mesh hit only counts
+ * if it is strictly closer (AccelerationStruct.cpp:307). */
+RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float bound, int* stk, int stride, int sp0,
                          bool& found, float& bestT, uint32_t& bestG, float& bw0, float& bw1, float& bw2) {
     found = false;
     bestT = FLT_MAX;
     bestG = 0; bw0 = bw1 = bw2 = 0.f;
+    const float slack = prune_slack(r, m.delta);
     int sp = sp0;
-    int link = root;
+    int link = m.root;
     for (;;) {
         if (link >= 0) {
             const float4* nd = sc.mnodes + 4 * (size_t)link;
@@ -64,8 +84,12 @@ RT_DEV void mesh_closest(const DScene& sc, int root, const Ray& r, int* stk, int
             bool hL = slab(r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
             bool hR = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
             int left = __float_as_int(d.x), right = __float_as_int(d.y);
+            float lim = fminf(bound, bestT);
+            bool nearLeft = tL <= tR;                         /* AccelerationStruct.cpp:273 */
+            hL = hL && !beyond(tL, slack, lim);
+            hR = hR && !beyond(tR, slack, lim);
             if (hL && hR) {
-                if (tL <= tR) { stk[lds_index(sp++, stride)] = right; link = left; }
+                if (nearLeft) { stk[lds_index(sp++, stride)] = right; link = left; }
                 else { stk[lds_index(sp++, stride)] = left; link = right; }
                 continue;
             }
@@ -87,13 +111,13 @@ RT_DEV void mesh_closest(const DScene& sc, int root, const Ray& r, int* stk, int
     }
 }
 
-/* Same candidate set, shadow use: returns 2 when some triangle is hit at t <= lightDistance
- * (the leaf loop of intersectObjects then returns at once, AccelerationStruct.cpp:309),
- * 1 when the mesh is hit only beyond it, 0 when not at all. */
-RT_DEV int mesh_any(const DScene& sc, int root, const Ray& r, float lightDistance, int* stk, int stride, int sp0) {
+/* Same candidate set, shadow use: is any triangle hit at t <= bound? (Order does not matter for
+ * that answer, so the nearer child goes first to find an occluder early.) With prune=false and
+ * bound just below FLT_MAX this is "does RayTraceMesh::intersect return a hit at all". */
+RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound, bool prune, int* stk, int stride, int sp0) {
+    const float slack = prune ? prune_slack(r, m.delta) : INFINITY;
     int sp = sp0;
-    int link = root;
-    int res = 0;
+    int link = m.root;
     for (;;) {
         if (link >= 0) {
             const float4* nd = sc.mnodes + 4 * (size_t)link;
@@ -102,7 +126,14 @@ RT_DEV int mesh_any(const DScene& sc, int root, const Ray& r, float lightDistanc
             bool hL = slab(r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
             bool hR = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
             int left = __float_as_int(d.x), right = __float_as_int(d.y);
-            if (hL && hR) { stk[lds_index(sp++, stride)] = right; link = left; continue; }
+            bool nearLeft = tL <= tR;
+            hL = hL && !beyond(tL, slack, bound);
+            hR = hR && !beyond(tR, slack, bound);
+            if (hL && hR) {
+                if (nearLeft) { stk[lds_index(sp++, stride)] = right; link = left; }
+                else { stk[lds_index(sp++, stride)] = left; link = right; }
+                continue;
+            }
             if (hL) { link = left; continue; }
             if (hR) { link = right; continue; }
         } else {
@@ -110,16 +141,13 @@ RT_DEV int mesh_any(const DScene& sc, int root, const Ray& r, float lightDistanc
             for (uint32_t i = 0; i < lf.y; i++) {
                 const float4* q = sc.tri + 4 * (size_t)(lf.x + i);
                 float t, w0, w1, w2;
-                if (tri_test(r, q[0], q[1], q[2], q[3], t, w0, w1, w2)) {
-                    if (t <= lightDistance) return 2;
-                    if (t < FLT_MAX) res = 1;
-                }
+                if (tri_test(r, q[0], q[1], q[2], q[3], t, w0, w1, w2) && t <= bound) return true;
             }
         }
         if (sp == sp0) break;
         link = stk[lds_index(--sp, stride)];
     }
-    return res;
+    return false;
 }
 
 /* BVH_Node::intersectObjects(ray) with stopAtFirst=false (AccelerationStruct.cpp:286-337):
@@ -166,7 +194,7 @@ RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
                 } else {
                     DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
                     bool found; float t; uint32_t g; float w0, w1, w2;
-                    mesh_closest(sc, m.root, r, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
+                    mesh_closest(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
                     if (found && t < best.t) {
                         best.exists = 1; best.t = t; best.obj = ord; kind = 2;
                         bestG = g; bw0 = w0; bw1 = w1; bw2 = w2; best.mat = m.material;
@@ -196,8 +224,15 @@ RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
 /* BVH_Node::intersectObjects(ray, lightDistance, stopAtFirst=true) as Scene::isInShadow uses it
  * (Scene.h:160-168): leaves in left-first order; the first leaf whose result exists decides --
  * occluded iff that result has t <= lightDistance, which inside a leaf is reached exactly when
- * some object of the leaf is hit at t <= lightDistance (AccelerationStruct.cpp:293-311,326-330). */
-RT_DEV bool occluded(const DScene& sc, const Ray& r, float lightDistance, int* stk, int stride) {
+ * some object of the leaf is hit at t <= lightDistance (AccelerationStruct.cpp:293-311,326-330).
+ * mode 0: walk the leaves looking for an object hit at t <= lightDistance (meshes pruned by the
+ *         light distance). Returns the number of leaves visited before the occluding one, or -1.
+ * mode 1: for the first `limit` leaves, is any object hit at all (any t)? Such a leaf returns an
+ *         existing result beyond the light and hides the occluder behind it
+ *         (AccelerationStruct.cpp:327-330). Returns 1 / 0. */
+RT_DEV int shadow_walk(const DScene& sc, const Ray& r, float lightDistance, int mode, int limit, int* stk, int stride) {
+    const float bound = mode == 0 ? lightDistance : 3.4028233e38f;   /* largest float below FLT_MAX: t < FLT_MAX */
+    int visited = 0;
     int sp = 0;
     int link = sc.top_root;
     for (;;) {
@@ -212,37 +247,38 @@ RT_DEV bool occluded(const DScene& sc, const Ray& r, float lightDistance, int* s
             if (hL) { link = left; continue; }
             if (hR) { link = right; continue; }
         } else {
+            if (mode == 1 && visited >= limit) return 0;
             uint2 lf = sc.tleaves[-1 - link];
-            bool leafExists = false;
             for (uint32_t i = 0; i < lf.y; i++) {
                 int ord = (int)sc.titems[lf.x + i];
+                bool hit;
                 if (ord < sc.n_squares) {
                     const float4* q = sc.squares + 4 * ord;
                     float t, u, v;
-                    if (square_test(r, q[0], q[1], q[2], q[3], t, u, v) && t < FLT_MAX) {
-                        if (t <= lightDistance) return true;
-                        leafExists = true;
-                    }
+                    hit = square_test(r, q[0], q[1], q[2], q[3], t, u, v) && t <= bound;
                 } else if (ord < sc.n_squares + sc.n_spheres) {
                     const float4* q = sc.spheres + 2 * (ord - sc.n_squares);
                     float t; F3 n;
-                    if (sphere_test(r, q[0], t, n) && t < FLT_MAX) {
-                        if (t <= lightDistance) return true;
-                        leafExists = true;
-                    }
+                    hit = sphere_test(r, q[0], t, n) && t <= bound;
                 } else {
                     DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
-                    int res = mesh_any(sc, m.root, r, lightDistance, stk, stride, sc.top_cap);
-                    if (res == 2) return true;
-                    if (res == 1) leafExists = true;
+                    hit = mesh_any(sc, m, r, bound, mode == 0, stk, stride, sc.top_cap);
                 }
+                if (hit) return mode == 0 ? visited : 1;
             }
-            if (leafExists) return false;
+            visited++;
         }
         if (sp == 0) break;
         link = stk[lds_index(--sp, stride)];
     }
-    return false;
+    return mode == 0 ? -1 : 0;
+}
+
+RT_DEV bool occluded(const DScene& sc, const Ray& r, float lightDistance, int* stk, int stride) {
+    int before = shadow_walk(sc, r, lightDistance, 0, 0, stk, stride);
+    if (before < 0) return false;
+    if (before == 0) return true;
+    return shadow_walk(sc, r, lightDistance, 1, before, stk, stride) == 0;
 }
 
 /* Scene::isInShadow, Scene.h:160-168 */
@@ -508,55 +544,195 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
     }
 }
 
-/* Scene::sampleSphereLight (Scene.h:110-134) with one lane per light sample. Lane index =
- * (record * n_lights + light) * S + i. cnt[record*n_lights+light] receives the number of
- * occluded samples (shadowCount). */
+/* ------------------------------------------------------------------ persistent shadow kernel
+ * Scene::sampleSphereLight + Scene::isInShadow (Scene.h:110-134,160-168) for every (diffuse record,
+ * light, sample): ray index = (record*n_lights + light)*S + i. cnt[record*n_lights+light] receives
+ * the number of occluded samples (shadowCount).
+ *
+ * Shadow rays end at very different times (an occluder is usually found after a few nodes, an
+ * unoccluded ray walks its whole box chain), so one ray per lane leaves most lanes of a wave idle.
+ * Here every wave is persistent: lanes whose ray has ended are refilled from a global work counter
+ * (one wave-aggregated atomicAdd, lanes ranked with a ballot), and each lane runs a small state
+ * machine -- top level (ST_TOP) or inside one mesh tree (ST_MESH) -- whose per-lane stack lives in LDS.
+ * The traversal semantics are those of shadow_walk()/mesh_any() above (mode 0 / mode 1). */
+#define ST_IDLE 0
+#define ST_TOP 1
+#define ST_MESH 2
+#define LINK_NONE ((int)0x80000000)
+#define RT_REFILL_MIN 20      /* refill once this many lanes are idle */
+#define RT_MESH_STEPS 8       /* mesh steps between two refill checks */
+
+struct ShadowLane {
+    Ray r;
+    float bound;        /* lightDistance (mode 0) or just below FLT_MAX (mode 1) */
+    float lightDistance;
+    float slack;        /* prune slack of the current mesh (inf in mode 1) */
+    uint32_t key;       /* record*n_lights + light */
+    int st, mode, visited, limit;
+    int tlink, tsp;     /* top-level cursor and stack pointer */
+    uint32_t top_pos, top_end;
+    int leaf_open;
+    int link, msp;      /* mesh cursor and stack pointer */
+    uint32_t tri_pos, tri_end;
+};
+
+RT_DEV void shadow_restart(const DScene& sc, ShadowLane& s, int mode, int limit) {
+    s.mode = mode; s.limit = limit; s.visited = 0;
+    s.bound = mode == 0 ? s.lightDistance : 3.4028233e38f;
+    s.tlink = sc.top_root; s.tsp = 0; s.top_pos = s.top_end = 0; s.leaf_open = 0;
+    s.st = ST_TOP;
+}
+RT_DEV void shadow_finish(ShadowLane& s, bool occ, uint32_t* cnt) {
+    if (occ) atomicAdd(cnt + s.key, 1u);
+    s.st = ST_IDLE;
+}
+/* an object of the current leaf is hit at t <= bound */
+RT_DEV void shadow_on_hit(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
+    if (s.mode == 1) { shadow_finish(s, false, cnt); return; }       /* an earlier leaf returns a result beyond the light */
+    if (s.visited == 0) { shadow_finish(s, true, cnt); return; }
+    shadow_restart(sc, s, 1, s.visited);
+}
+/* top-level state machine: runs until the ray ends or enters a mesh tree */
+RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int stride, uint32_t* cnt) {
+    for (;;) {
+        if (s.top_pos < s.top_end) {
+            int ord = (int)sc.titems[s.top_pos++];
+            if (ord < sc.n_squares) {
+                const float4* q = sc.squares + 4 * ord;
+                float t, u, v;
+                if (square_test(s.r, q[0], q[1], q[2], q[3], t, u, v) && t <= s.bound) { shadow_on_hit(sc, s, cnt); if (s.st == ST_IDLE) return; }
+            } else if (ord < sc.n_squares + sc.n_spheres) {
+                const float4* q = sc.spheres + 2 * (ord - sc.n_squares);
+                float t; F3 n;
+                if (sphere_test(s.r, q[0], t, n) && t <= s.bound) { shadow_on_hit(sc, s, cnt); if (s.st == ST_IDLE) return; }
+            } else {
+                DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
+                s.slack = s.mode == 0 ? prune_slack(s.r, m.delta) : INFINITY;
+                s.link = m.root; s.msp = sc.top_cap; s.tri_pos = s.tri_end = 0;
+                s.st = ST_MESH;
+                return;
+            }
+            continue;
+        }
+        if (s.leaf_open) { s.leaf_open = 0; s.visited++; }
+        if (s.tlink == LINK_NONE) {
+            if (s.tsp == 0) { shadow_finish(s, s.mode == 1, cnt); return; }   /* mode 0: no occluder; mode 1: nothing hides it */
+            s.tlink = stk[lds_index(--s.tsp, stride)];
+        }
+        if (s.tlink >= 0) {
+            const float4* nd = sc.tnodes + 4 * (size_t)s.tlink;
+            float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+            float tL, tR;
+            bool hL = slab(s.r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
+            bool hR = slab(s.r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
+            int left = __float_as_int(d.x), right = __float_as_int(d.y);
+            if (hL && hR) { stk[lds_index(s.tsp++, stride)] = right; s.tlink = left; }
+            else if (hL) s.tlink = left;
+            else if (hR) s.tlink = right;
+            else s.tlink = LINK_NONE;
+        } else {
+            if (s.mode == 1 && s.visited >= s.limit) { shadow_finish(s, true, cnt); return; }
+            uint2 lf = sc.tleaves[-1 - s.tlink];
+            s.top_pos = lf.x; s.top_end = lf.x + lf.y; s.leaf_open = 1;
+            s.tlink = LINK_NONE;
+        }
+    }
+}
+/* one unit of work inside a mesh tree: a triangle test, a node (two slab tests), a leaf fetch or a pop */
+RT_DEV void shadow_mesh_step(const DScene& sc, ShadowLane& s, int* stk, int stride, uint32_t* cnt) {
+    if (s.tri_pos < s.tri_end) {
+        const float4* q = sc.tri + 4 * (size_t)s.tri_pos;
+        s.tri_pos++;
+        float t, w0, w1, w2;
+        if (tri_test(s.r, q[0], q[1], q[2], q[3], t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
+    } else if (s.link == LINK_NONE) {
+        if (s.msp == sc.top_cap) s.st = ST_TOP;                     /* mesh done without a hit: next object of the leaf */
+        else s.link = stk[lds_index(--s.msp, stride)];
+    } else if (s.link >= 0) {
+        const float4* nd = sc.mnodes + 4 * (size_t)s.link;
+        float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+        float tL, tR;
+        bool hL = slab(s.r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
+        bool hR = slab(s.r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
+        int left = __float_as_int(d.x), right = __float_as_int(d.y);
+        bool nearLeft = tL <= tR;
+        hL = hL && !beyond(tL, s.slack, s.bound);
+        hR = hR && !beyond(tR, s.slack, s.bound);
+        if (hL && hR) {
+            stk[lds_index(s.msp++, stride)] = nearLeft ? right : left;
+            s.link = nearLeft ? left : right;
+        } else if (hL) s.link = left;
+        else if (hR) s.link = right;
+        else s.link = LINK_NONE;
+    } else {
+        uint2 lf = sc.mleaves[-1 - s.link];
+        s.tri_pos = lf.x; s.tri_end = lf.x + lf.y;
+        s.link = LINK_NONE;
+    }
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
                                                      const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
-                                                     uint32_t* cnt, Counters* ctr) {
+                                                     uint32_t* cnt, Counters* ctr, unsigned long long* next) {
     extern __shared__ int s_stack[];
-    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
-    bool active = idx < total;
     int* stk = s_stack + threadIdx.x;
     const int stride = blockDim.x;
-    uint32_t key = 0xFFFFFFFFu;
-    bool occ = false;
-    if (active) {
-        key = (uint32_t)(idx / (unsigned)S);
-        uint32_t i = (uint32_t)(idx % (unsigned)S);
-        uint32_t rec = key / (uint32_t)sc.n_lights, li = key % (uint32_t)sc.n_lights;
-        const float4* q = reinterpret_cast<const float4*>(drec + rec);
-        float4 q0 = q[0], q3 = q[3];
-        F3 P = f3(q0.x, q0.y, q0.z);
-        DLight L = sc.lights[li];
-        F3 lp = f3(L.pos[0], L.pos[1], L.pos[2]);
-        if (fr.shadow_mode == 0) {
-            uint32_t pixel = __float_as_uint(q3.z), sample = __float_as_uint(q3.w);
-            unsigned long long code = dcode[rec];
-            uint32_t ky = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 0) % 360u;   /* randY first, Scene.h:115 */
-            uint32_t kx = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 1) % 360u;
-            double sinY = sc.sincos[ky], cosY = sc.sincos[360 + ky];
-            double sinX = sc.sincos[kx], cosX = sc.sincos[360 + kx];
-            float p1 = (float)(-sinY), p2 = (float)cosY;                                 /* Scene.h:119 */
-            float p0 = (float)(-sinX * (double)p2);                                      /* Scene.h:121 */
-            p2 = (float)(cosX * (double)p2);                                             /* Scene.h:122 */
-            lp = add(lp, mul(L.radius, f3(p0, p1, p2)));                                 /* Scene.h:124-126 */
+    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    const int lane = __lane_id();
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    ShadowLane s;
+    s.st = ST_IDLE;
+    bool exhausted = false;
+    unsigned long long traced = 0;      /* lane 0 only */
+    for (;;) {
+        unsigned long long idle = __ballot(s.st == ST_IDLE);
+        if (!exhausted && (__popcll(idle) >= RT_REFILL_MIN)) {
+            uint32_t n = __popcll(idle);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(next, (unsigned long long)n);
+            base = __shfl(base, 0);
+            if (base + n >= total) exhausted = true;
+            if (lane == 0 && base < total) traced += (base + n <= total) ? n : (total - base);
+            unsigned long long idx = base + __popcll(idle & lt);
+            if (s.st == ST_IDLE && idx < total) {
+                s.key = (uint32_t)(idx / (unsigned)S);
+                uint32_t i = (uint32_t)(idx % (unsigned)S);
+                uint32_t rec = s.key / (uint32_t)sc.n_lights, li = s.key % (uint32_t)sc.n_lights;
+                const float4* q = reinterpret_cast<const float4*>(drec + rec);
+                float4 q0 = q[0], q3 = q[3];
+                F3 P = f3(q0.x, q0.y, q0.z);
+                DLight L = sc.lights[li];
+                F3 lp = f3(L.pos[0], L.pos[1], L.pos[2]);
+                if (fr.shadow_mode == 0) {
+                    uint32_t pixel = __float_as_uint(q3.z), sample = __float_as_uint(q3.w);
+                    unsigned long long code = dcode[rec];
+                    uint32_t ky = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 0) % 360u;   /* randY first, Scene.h:115 */
+                    uint32_t kx = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 1) % 360u;
+                    double sinY = sc.sincos[ky], cosY = sc.sincos[360 + ky];
+                    double sinX = sc.sincos[kx], cosX = sc.sincos[360 + kx];
+                    float p1 = (float)(-sinY), p2 = (float)cosY;                                 /* Scene.h:119 */
+                    float p0 = (float)(-sinX * (double)p2);                                      /* Scene.h:121 */
+                    p2 = (float)(cosX * (double)p2);                                             /* Scene.h:122 */
+                    lp = add(lp, mul(L.radius, f3(p0, p1, p2)));                                 /* Scene.h:124-126 */
+                }
+                F3 dir = sub(lp, P);                                                             /* Scene.h:161-164 */
+                s.lightDistance = len(dir);
+                dir = normalized(dir);
+                s.r = make_ray(add(P, mul(0.001f, dir)), dir);
+                shadow_restart(sc, s, 0, 0);
+            }
         }
-        occ = in_shadow(sc, P, lp, stk, stride);
+        if (__ballot(s.st != ST_IDLE) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (s.st == ST_TOP) shadow_advance_top(sc, s, stk, stride, cnt);
+#pragma unroll 1
+        for (int k = 0; k < RT_MESH_STEPS; k++) {
+            if (s.st == ST_MESH) shadow_mesh_step(sc, s, stk, stride, cnt);
+        }
     }
-    /* per-(record,light) reduction inside the wave, then one atomic per segment */
-    unsigned long long am = __ballot(active);
-    if (__lane_id() == 0 && am) atomicAdd(&ctr->rays_shadow, (unsigned long long)__popcll(am));
-    unsigned long long todo = am;
-    while (todo) {
-        int leader = __ffsll((long long)todo) - 1;
-        uint32_t k0 = __shfl(key, leader);
-        unsigned long long same = __ballot(active && key == k0);
-        unsigned long long hit = __ballot(active && key == k0 && occ);
-        if (__lane_id() == leader && hit) atomicAdd(cnt + k0, (uint32_t)__popcll(hit));
-        todo &= ~same;
-    }
+    if (lane == 0 && traced) atomicAdd(&ctr->rays_shadow, traced);
 }
 
 /* Scene::phong (Scene.h:90-108) + the shadow factor of Scene.h:210-222. */

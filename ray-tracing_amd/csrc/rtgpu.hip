@@ -55,6 +55,7 @@ struct rt_ctx {
     DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf;
     uint32_t batch = 1u << 20;
     bool debug = false;
+    int persistent_blocks = 256 * 32;
     size_t stack_cap = 0;       /* states */
     Counters* h_ctr = nullptr;  /* pinned */
     rt_stats stats{};
@@ -240,15 +241,16 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         /* 3. shadow + Phong for the diffuse records of this batch */
         if (n_diff && L > 0) {
             HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
+            /* persistent waves: enough 64-lane blocks to fill the chip, never more than the work */
             unsigned long long threads = (unsigned long long)n_diff * L * S;
-            unsigned long long blocks = (threads + RT_BLOCK - 1) / RT_BLOCK;
-            if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "shadow grid too large");
+            unsigned long long blocks = std::min<unsigned long long>((threads + RT_BLOCK - 1) / RT_BLOCK, (unsigned long long)c->persistent_blocks);
+            HIP_TRY(c, hipMemsetAsync(&d_ctr->work, 0, sizeof(unsigned long long), c->stream));
             EventPair* e2 = next_event(c, 1);
             if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
             HIP_TRY(c, hipEventRecord(e2->a, c->stream));
             hipLaunchKernelGGL(k_shadow, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds, c->stream, c->sc, c->fr,
                                static_cast<const DiffuseRec*>(c->drec.p), static_cast<const unsigned long long*>(c->dcode.p), n_diff, S,
-                               static_cast<uint32_t*>(c->cnt.p), d_ctr);
+                               static_cast<uint32_t*>(c->cnt.p), d_ctr, &d_ctr->work);
             HIP_TRY(c, hipEventRecord(e2->b, c->stream));
         }
         if (n_diff) {
@@ -360,6 +362,13 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
     const char* b = getenv("RT_BATCH");
     if (b && atoi(b) >= 1024) c->batch = (uint32_t)atoi(b);
     c->debug = getenv("RT_DEBUG") != nullptr;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            c->persistent_blocks = prop.multiProcessorCount * 32;    /* 32 one-wave blocks per CU is the residency cap */
+        const char* pb = getenv("RT_PERSISTENT_BLOCKS");
+        if (pb && atoi(pb) > 0) c->persistent_blocks = atoi(pb);
+    }
     *out = c;
     return RT_OK;
 }
@@ -434,6 +443,10 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         }
         meshes[mi].root = glob(m.root);
         meshes[mi].material = m.material;
+        float amax = 0.f;
+        for (int64_t v = 0; v < 3 * m.vert_count; v++) amax = std::max(amax, std::fabs(d->positions[3 * m.vert_first + v]));
+        meshes[mi].delta = 8e-4f * amax + 1e-5f;
+        meshes[mi].pad = 0;
     }
     if (d->n_verts > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "too many vertices");
     std::vector<float> normals(d->normals, d->normals + 3 * d->n_verts);
