@@ -62,11 +62,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-
     rt = importlib.import_module("ray-tracing_amd")
+    rtd = importlib.import_module("ray-tracing_amd.dist")
+    rtd.init("nccl", local_rank)          # RCCL; no-op for one rank
+
     W, H = args.width, args.height
     name = f"soup:{args.ntris}"
     t0 = time.time()
@@ -79,7 +78,7 @@ def main():
     cam = rt.default_camera(W / H)
     ctx.set_camera(cam)
     params = rt.make_params(W, H, spp=args.spp, max_depth=args.depth, light_samples=35, shadow_mode=0, jitter=1, seed=0)
-    tiles = rt.interleaved_tiles(W, H, rank, world, 32)
+    tiles = rtd.shard_tiles(W, H, rank, world, 32)
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step():
@@ -87,8 +86,7 @@ def main():
         for t in tiles:
             ctx.render_tile(*t)
         ctx.resolve_device(frame.data_ptr())       # runs the queued tiles, writes this rank's pixels
-        if world > 1:
-            dist.all_reduce(frame, op=dist.ReduceOp.SUM)   # RCCL: disjoint tiles -> gather
+        rtd.gather_frame(frame)                    # RCCL all-reduce: disjoint tiles -> gather
         return ctx.stats()
 
     def fence():
@@ -116,13 +114,9 @@ def main():
         n_closest += st.launches_closest
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        rr = torch.tensor([rays, prim, sec, shad], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-        rays, prim, sec, shad = [int(x) for x in rr.tolist()]
+    dev = f"cuda:{local_rank}"
+    elapsed = rtd.max_over_ranks(elapsed, dev)
+    rays, prim, sec, shad = rtd.sum_counters([rays, prim, sec, shad], dev)
     checksum = float(frame.double().sum().item())
 
     if rank == 0:

@@ -38,6 +38,7 @@ struct Counters {
     unsigned long long rays_primary, rays_secondary, rays_shadow, nonfinite;
     unsigned long long work;        /* next unclaimed shadow-ray index of the running k_shadow launch */
     unsigned long long pad2;
+    unsigned long long sh_node_steps, sh_tri_steps, sh_other_steps, sh_loop_iters;   /* RT_COUNT=1 diagnostics */
 };
 struct TileD { int32_t x0, y0, w, h; unsigned long long first; };
 struct CameraD { double pinv[16], mvinv[16]; float eye[3]; float pad; };
@@ -559,8 +560,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
 #define ST_TOP 1
 #define ST_MESH 2
 #define LINK_NONE ((int)0x80000000)
-#define RT_REFILL_MIN 20      /* refill once this many lanes are idle */
-#define RT_MESH_STEPS 8       /* mesh steps between two refill checks */
+#define RT_REFILL_MIN 8       /* refill once this many lanes are idle */
+#define RT_NODE_STEPS 16      /* node-phase steps between two refill checks */
+#define RT_TRI_STEPS 4        /* triangle-phase steps per round */
 
 struct ShadowLane {
     Ray r;
@@ -638,18 +640,17 @@ RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int st
         }
     }
 }
-/* one unit of work inside a mesh tree: a triangle test, a node (two slab tests), a leaf fetch or a pop */
-RT_DEV void shadow_mesh_step(const DScene& sc, ShadowLane& s, int* stk, int stride, uint32_t* cnt) {
-    if (s.tri_pos < s.tri_end) {
-        const float4* q = sc.tri + 4 * (size_t)s.tri_pos;
-        s.tri_pos++;
-        float t, w0, w1, w2;
-        if (tri_test(s.r, q[0], q[1], q[2], q[3], t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
-    } else if (s.link == LINK_NONE) {
-        if (s.msp == sc.top_cap) s.st = ST_TOP;                     /* mesh done without a hit: next object of the leaf */
-        else s.link = stk[lds_index(--s.msp, stride)];
-    } else if (s.link >= 0) {
-        const float4* nd = sc.mnodes + 4 * (size_t)s.link;
+/* one traversal unit inside a mesh tree for a lane with no pending triangle: pop if the cursor is
+ * empty, then either fetch a leaf's triangle range or process one inner node (two slab tests) and
+ * move to the next link straight away */
+RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stride) {
+    int link = s.link;
+    if (link == LINK_NONE) {
+        if (s.msp == sc.top_cap) { s.st = ST_TOP; return; }        /* mesh done without a hit: next object of the leaf */
+        link = stk[lds_index(--s.msp, stride)];
+    }
+    if (link >= 0) {
+        const float4* nd = sc.mnodes + 4 * (size_t)link;
         float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
         float tL, tR;
         bool hL = slab(s.r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
@@ -660,21 +661,35 @@ RT_DEV void shadow_mesh_step(const DScene& sc, ShadowLane& s, int* stk, int stri
         hR = hR && !beyond(tR, s.slack, s.bound);
         if (hL && hR) {
             stk[lds_index(s.msp++, stride)] = nearLeft ? right : left;
-            s.link = nearLeft ? left : right;
-        } else if (hL) s.link = left;
-        else if (hR) s.link = right;
-        else s.link = LINK_NONE;
-    } else {
-        uint2 lf = sc.mleaves[-1 - s.link];
-        s.tri_pos = lf.x; s.tri_end = lf.x + lf.y;
-        s.link = LINK_NONE;
+            link = nearLeft ? left : right;
+        } else if (hL) link = left;
+        else if (hR) link = right;
+        else if (s.msp > sc.top_cap) link = stk[lds_index(--s.msp, stride)];
+        else link = LINK_NONE;
     }
+    if (link < 0 && link != LINK_NONE) {
+        uint2 lf = sc.mleaves[-1 - link];
+        s.tri_pos = lf.x; s.tri_end = lf.x + lf.y;
+        link = LINK_NONE;
+    }
+    s.link = link;
+}
+RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
+    const float4* q = sc.tri + 4 * (size_t)s.tri_pos;
+    s.tri_pos++;
+    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    if (tri_surely_missed(s.r, q0, q1, q2, q3)) return;
+    float t, w0, w1, w2;
+    if (tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
 
+/* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
+ * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
                                                      const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
-                                                     uint32_t* cnt, Counters* ctr, unsigned long long* next) {
+                                                     uint32_t* cnt, Counters* ctr, unsigned long long* next, int count_steps) {
     extern __shared__ int s_stack[];
+    unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0;
     int* stk = s_stack + threadIdx.x;
     const int stride = blockDim.x;
     const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
@@ -682,6 +697,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     ShadowLane s;
     s.st = ST_IDLE;
+    s.tri_pos = s.tri_end = 0;
     bool exhausted = false;
     unsigned long long traced = 0;      /* lane 0 only */
     for (;;) {
@@ -719,6 +735,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const
                 s.lightDistance = len(dir);
                 dir = normalized(dir);
                 s.r = make_ray(add(P, mul(0.001f, dir)), dir);
+                s.tri_pos = s.tri_end = 0;
                 shadow_restart(sc, s, 0, 0);
             }
         }
@@ -727,12 +744,30 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const
             continue;
         }
         if (s.st == ST_TOP) shadow_advance_top(sc, s, stk, stride, cnt);
+        /* node phase */
 #pragma unroll 1
-        for (int k = 0; k < RT_MESH_STEPS; k++) {
-            if (s.st == ST_MESH) shadow_mesh_step(sc, s, stk, stride, cnt);
+        for (int k = 0; k < RT_NODE_STEPS; k++) {
+            bool walking = s.st == ST_MESH && !(s.tri_pos < s.tri_end);
+            bool waiting = s.st == ST_MESH && (s.tri_pos < s.tri_end);
+            unsigned long long mw = __ballot(walking), mt = __ballot(waiting);
+            if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
+            if (count_steps) { c_iter++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
+            if (walking) shadow_node_step(sc, s, stk, stride);
+        }
+        /* triangle phase */
+#pragma unroll 1
+        for (int k = 0; k < RT_TRI_STEPS; k++) {
+            bool pending = s.st == ST_MESH && (s.tri_pos < s.tri_end);
+            if (__ballot(pending) == 0ull) break;
+            if (count_steps) { c_iter++; if (pending) c_tri++; }
+            if (pending) shadow_tri_step(sc, s, cnt);
         }
     }
     if (lane == 0 && traced) atomicAdd(&ctr->rays_shadow, traced);
+    if (count_steps) {
+        atomicAdd(&ctr->sh_node_steps, c_node); atomicAdd(&ctr->sh_tri_steps, c_tri);
+        atomicAdd(&ctr->sh_other_steps, c_other); atomicAdd(&ctr->sh_loop_iters, c_iter);
+    }
 }
 
 /* Scene::phong (Scene.h:90-108) + the shadow factor of Scene.h:210-222. */

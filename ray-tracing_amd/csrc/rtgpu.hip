@@ -54,7 +54,7 @@ struct rt_ctx {
 
     DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf;
     uint32_t batch = 1u << 20;
-    bool debug = false;
+    bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 32;
     size_t stack_cap = 0;       /* states */
     Counters* h_ctr = nullptr;  /* pinned */
@@ -250,7 +250,7 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
             HIP_TRY(c, hipEventRecord(e2->a, c->stream));
             hipLaunchKernelGGL(k_shadow, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds, c->stream, c->sc, c->fr,
                                static_cast<const DiffuseRec*>(c->drec.p), static_cast<const unsigned long long*>(c->dcode.p), n_diff, S,
-                               static_cast<uint32_t*>(c->cnt.p), d_ctr, &d_ctr->work);
+                               static_cast<uint32_t*>(c->cnt.p), d_ctr, &d_ctr->work, c->count_steps ? 1 : 0);
             HIP_TRY(c, hipEventRecord(e2->b, c->stream));
         }
         if (n_diff) {
@@ -274,6 +274,9 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
     c->stats.rays_secondary += c->h_ctr->rays_secondary;
     c->stats.rays_shadow += c->h_ctr->rays_shadow;
     c->stats.nonfinite += c->h_ctr->nonfinite;
+    if (c->count_steps)
+        fprintf(stderr, "[rtgpu] shadow steps: node %llu tri %llu other %llu lane-iterations %llu rays %llu\n", c->h_ctr->sh_node_steps,
+                c->h_ctr->sh_tri_steps, c->h_ctr->sh_other_steps, c->h_ctr->sh_loop_iters, c->h_ctr->rays_shadow);
     for (size_t i = 0; i < c->ev_used; i++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) {
@@ -362,6 +365,7 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
     const char* b = getenv("RT_BATCH");
     if (b && atoi(b) >= 1024) c->batch = (uint32_t)atoi(b);
     c->debug = getenv("RT_DEBUG") != nullptr;
+    c->count_steps = getenv("RT_COUNT") != nullptr;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)

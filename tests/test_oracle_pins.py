@@ -1,0 +1,148 @@
+"""Pins the CPU oracle (test infrastructure) to what is known about the reference.
+
+The reference path cannot be compiled here (GL headers) and ships no tests, so the pins are
+(a) the GL-free reference sources compiled unmodified into oracle/_ref/libref.so and
+(b) the known answers SURVEY.md recorded from the compiled reference (scene values, BVH
+statistics, primary-hit ordinal, ray and work statistics).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+
+
+@pytest.fixture(scope="module")
+def final():
+    return O.Scene("final", 3, 12)
+
+
+def test_final_scene_known_values(final):
+    # sphere[2] = centre (20.1104, 15.0184, 23.5317), r 0.73828, diffuse
+    assert final.counts() == (1, 52, 31, 2)
+    c, r, m = final.sphere(2)
+    assert np.allclose(c, [20.1104, 15.0184, 23.5317], atol=5e-5)
+    assert abs(r - 0.73828) < 5e-6 and m.type == 0
+    # lights of Scene.h:824-836
+    p0, r0, _ = final.light(0)
+    p1, r1, _ = final.light(1)
+    assert list(p0) == [4.0, 0.0, 10.0] and r0 == 0.5 and list(p1) == [-6.0, 2.0, 1.25] and r1 == 10.75
+
+
+def test_final_scene_bvh_statistics(final):
+    # top level 15 nodes / 8 leaves / 84 objects, max 22 per leaf
+    leaf, cnt, _, items = final.tree(-1)
+    assert (len(leaf), int(leaf.sum()), len(items), int(cnt.max())) == (15, 8, 84, 22)
+    # gorilla 4879 nodes, 2440 leaves (432 empty), max leaf 33; flamingo 2201 / 1101 (263 empty) / 299
+    leaf, cnt, _, items = final.tree(0)
+    assert (len(leaf), int(leaf.sum()), int(((leaf == 1) & (cnt == 0)).sum()), int(cnt.max()), len(items)) == (4879, 2440, 432, 33, 3830)
+    leaf, cnt, _, items = final.tree(1)
+    assert (len(leaf), int(leaf.sum()), int(((leaf == 1) & (cnt == 0)).sum()), int(cnt.max()), len(items)) == (2201, 1101, 263, 299, 2544)
+
+
+def test_default_view_hits_the_mirror_sphere_and_ray_statistics(final):
+    # from the default camera every primary ray hits object ordinal 2;
+    # 39.4 rays per primary sample (2.2 radiance + 37.1 shadow), ~77 slab and ~102 triangle tests per ray (40x40)
+    rgb, prim, st, _ = final.render(O.default_camera(), O.make_params(40, 40, spp=1), threads=8)
+    assert np.all(prim[..., 0] == 2)
+    n = st.rays_primary
+    tot = st.rays_primary + st.rays_secondary + st.rays_shadow
+    assert n == 1600
+    assert abs(tot / n - 39.4) < 0.05
+    assert abs((st.rays_primary + st.rays_secondary) / n - 2.2) < 0.05
+    assert abs(st.rays_shadow / n - 37.1) < 0.1
+    assert abs(st.box_tests / tot - 77) < 1.0 and abs(st.tri_tests / tot - 102) < 1.0
+
+
+def test_hard_shadow_mode_is_thread_count_independent(final):
+    p = O.make_params(24, 24, spp=1, shadow_mode=1)
+    a, pa, _, _ = final.render(O.default_camera(), p, threads=1)
+    b, pb, _, _ = final.render(O.default_camera(), p, threads=8)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(pa, pb)
+    # the counter RNG makes the stochastic mode reproducible as well
+    p = O.make_params(16, 16, spp=2, jitter=1, seed=9)
+    a, _, _, _ = final.render(O.default_camera(), p, threads=1)
+    b, _, _, _ = final.render(O.default_camera(), p, threads=8)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_default_camera_closed_form():
+    # eye (0,0,6.1), looking down -z, f = cot(22.5 deg), pixel (0,0) top-left
+    cam = O.default_camera()
+    org, d = O.camera_rays(cam, O.make_params(480, 480, spp=1), 0, 0, 480, 480)
+    assert np.allclose(org, [0, 0, 6.1], atol=1e-6)
+    d = d.reshape(480, 480, 3)
+    f = 1.0 / np.tan(np.radians(22.5))
+    x, y = 100, 37
+    xn, yn = 2 * (x + 0.5) / 480 - 1, -(2 * (y + 0.5) / 480 - 1)
+    want = np.array([xn / f, yn / f, -1.0])
+    want /= np.linalg.norm(want)
+    assert np.allclose(d[y, x], want, atol=2e-6)
+    assert d[0, 0, 0] < 0 < d[0, 0, 1]          # top-left pixel looks left and up
+
+
+def test_scene_geometry_literals():
+    s = O.Scene("refraction", 3, 12)
+    v, m = s.square(0)
+    # setQuad(-1,-1,0 ...2,2); translate z-2; scale 80,80,1; rotate_x(-90): a floor at y = -2 spanning +-80
+    assert np.allclose(v[:, 1], -2.0, atol=1e-4) and np.allclose(np.abs(v[:, [0, 2]]), 80.0, atol=1e-3)
+    assert m.type == 3 and m.shininess == 16
+    c, r, m = s.sphere(0)
+    assert list(c) == [0.0, 0.0, 0.5] and r == 0.75 and m.type == 1 and abs(m.ior - 1.4) < 1e-7
+
+
+def test_quantisation_matches_main_cpp():
+    x = np.array([0.0, 0.5, 0.999, 1.0, 7.5, 1.0 / 255.0, -0.25], np.float32)
+    assert O.quantize(x).tolist() == [0, 127, 254, 255, 255, 1, -63]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libref.so not built (needs /root/reference)")
+def test_vector_primitives_match_the_compiled_reference():
+    """Vec3/Mat3/Line of the real reference, compiled unmodified, against the oracle's restatement
+    (exercised through rays: normalisation) and numpy float32 arithmetic in the same order."""
+    R = C.CDLL(REF_SO)
+    rng = np.random.default_rng(0)
+    out = np.zeros(20, np.float32)
+    for _ in range(300):
+        a = rng.normal(size=3).astype(np.float32) * np.float32(10 ** rng.uniform(-3, 3))
+        b = rng.normal(size=3).astype(np.float32)
+        s = np.float32(rng.normal())
+        R.ref_vec3_ops(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_float(float(s)), out.ctypes.data_as(C.c_void_p))
+        f = np.float32
+        dot = f(f(f(a[0] * b[0]) + f(a[1] * b[1])) + f(a[2] * b[2]))
+        assert out[0] == dot
+        L = f(np.sqrt(np.float64(f(f(f(a[0] * a[0]) + f(a[1] * a[1])) + f(a[2] * a[2])))))
+        assert out[4] == L
+        assert np.array_equal(out[5:8], (a / L).astype(np.float32))
+        # Line(a, b).direction() == the oracle's Ray normalisation: a ray towards b from the origin of an empty scene
+        d = (b / f(np.sqrt(np.float64(f(f(f(b[0] * b[0]) + f(b[1] * b[1])) + f(b[2] * b[2])))))).astype(np.float32)
+        assert np.array_equal(out[17:20], d)
+    # sky colour of an empty scene depends only on the normalised direction: oracle normalisation == reference Line
+    s = O.Scene()
+    s.build()
+    dirs = rng.normal(size=(64, 3)).astype(np.float32) * 3
+    rgb = s.trace(np.zeros((64, 3), np.float32), dirs, O.make_params(1, 1))
+    for i in range(64):
+        R.ref_vec3_ops(dirs[i].ctypes.data_as(C.c_void_p), dirs[i].ctypes.data_as(C.c_void_p), C.c_float(1.0), out.ctypes.data_as(C.c_void_p))
+        t = np.float32(0.5 * (np.float64(out[18]) + 1.0))
+        want = np.float32(1.0 - np.float64(t)) * np.float32(1.0) + t * np.array([0.5, 0.7, 1.0], np.float32)
+        assert np.array_equal(rgb[i], want.astype(np.float32))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libref.so not built (needs /root/reference)")
+def test_rotmatrix_matches_the_compiled_trackball():
+    R = C.CDLL(REF_SO)
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        q = rng.normal(size=4).astype(np.float32)
+        q /= np.linalg.norm(q)
+        a = np.zeros(16, np.float32)
+        b = np.zeros(16, np.float32)
+        R.ref_build_rotmatrix(q.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p))
+        O.lib().orc_rotmatrix(q.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
