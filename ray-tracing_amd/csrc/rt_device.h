@@ -66,11 +66,10 @@ struct DLight { float pos[3]; float radius; float color[3]; float pad; };
 struct DMesh { int32_t root; int32_t material; float delta; int32_t pad; };   /* delta: see prune_slack() */
 
 struct DScene {
-    const float4* tri;          /* 4 x float4 per triangle, leaf order: (c0,D) (c1,area) (c2,-) (n,-) */
+    const float4* tri;          /* 4 x float4 per triangle, leaf order: (c0,D) (c1,area) (c2,last-in-leaf flag) (n,-) */
     const uint4* tri_ids;       /* (v0, v1, v2 global vertex ids, index into Mesh::triangles), leaf order */
     const float* normals;       /* 3 per vertex */
-    const float4* mnodes;       /* 4 x float4 per inner node, links made global */
-    const uint2* mleaves;       /* (first, count) into tri, global */
+    const float4* mnodes;       /* 4 x float4 per inner node; child links encoded as in rt_kernels.h (LINK_*) */
     const DMesh* meshes;
     const float4* tnodes;
     const uint2* tleaves;
@@ -96,32 +95,26 @@ RT_DEV Ray make_ray(F3 o, F3 d) {
     return r;
 }
 
-/* AABB::intersect, AccelerationStruct.cpp:13-30 (tMin = 0, tMax = 100, NaN-ignoring max/min). */
+/* AABB::intersect, AccelerationStruct.cpp:13-30 (tMin = 0, tMax = 100), written without branches so
+ * that a node's loads are issued together instead of one memory round trip per axis:
+ *  - std::max(tMin,t0) = (tMin<t0)?t0:tMin and std::min(tMax,t1) = (t1<tMax)?t1:tMax ignore a NaN
+ *    t0/t1 (tMin/tMax are never NaN), which is exactly fmaxf/fminf (v_max_f32/v_min_f32);
+ *  - tMin only grows and tMax only shrinks, so the per-axis `if (tMin > tMax) return false` of the
+ *    reference is equivalent to one test after the third axis;
+ *  - the swap on invD < 0 selects the same two products either way. */
 RT_DEV bool slab(const Ray& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float& tEnter) {
-    float tMin = 0.0f, tMax = 100.0f;
-    {
-        float t0 = (mnx - r.o.x) * r.inv.x, t1 = (mxx - r.o.x) * r.inv.x;
-        if (r.inv.x < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-        tMin = (tMin < t0) ? t0 : tMin;
-        tMax = (t1 < tMax) ? t1 : tMax;
-        if (tMin > tMax) return false;
-    }
-    {
-        float t0 = (mny - r.o.y) * r.inv.y, t1 = (mxy - r.o.y) * r.inv.y;
-        if (r.inv.y < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-        tMin = (tMin < t0) ? t0 : tMin;
-        tMax = (t1 < tMax) ? t1 : tMax;
-        if (tMin > tMax) return false;
-    }
-    {
-        float t0 = (mnz - r.o.z) * r.inv.z, t1 = (mxz - r.o.z) * r.inv.z;
-        if (r.inv.z < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-        tMin = (tMin < t0) ? t0 : tMin;
-        tMax = (t1 < tMax) ? t1 : tMax;
-        if (tMin > tMax) return false;
-    }
+    float ax = (mnx - r.o.x) * r.inv.x, bx = (mxx - r.o.x) * r.inv.x;
+    float ay = (mny - r.o.y) * r.inv.y, by = (mxy - r.o.y) * r.inv.y;
+    float az = (mnz - r.o.z) * r.inv.z, bz = (mxz - r.o.z) * r.inv.z;
+    bool sx = r.inv.x < 0.0f, sy = r.inv.y < 0.0f, sz = r.inv.z < 0.0f;
+    float tMin = fmaxf(0.0f, sx ? bx : ax);
+    float tMax = fminf(100.0f, sx ? ax : bx);
+    tMin = fmaxf(tMin, sy ? by : ay);
+    tMax = fminf(tMax, sy ? ay : by);
+    tMin = fmaxf(tMin, sz ? bz : az);
+    tMax = fminf(tMax, sz ? az : bz);
     tEnter = tMin;
-    return true;
+    return !(tMin > tMax);
 }
 
 /* Triangle::getIntersection (Triangle.h:86-121) on a record precomputed at upload:

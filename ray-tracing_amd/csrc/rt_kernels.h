@@ -50,6 +50,13 @@ struct HitD { int exists; float t; int obj; int tri; F3 n; F3 pos; float u, v; i
 
 RT_DEV int lds_index(int k, int stride) { return k * stride; }
 
+/* Child links of the mesh trees on the device: >= 0 inner node; LINK_EMPTY a leaf without triangles;
+ * <= -2 a leaf whose triangles start at record -2-link (the last record of a leaf carries a flag in
+ * word 2.w), so that reaching a leaf costs no extra fetch; LINK_NONE = no link. */
+#define LINK_EMPTY (-1)
+#define LINK_NONE ((int)0x80000000)
+RT_DEV uint32_t leaf_first(int link) { return (uint32_t)(-2 - link); }
+
 /* Result-preserving pruning. A triangle record is the mesh triangle scaled by 1.0001f about the
  * origin (Mesh.cpp:107-109) and accepted with a barycentric tolerance (Triangle.h:105), so its hit
  * point can lie up to ~1e-4*|coordinate| outside the (unscaled) box of its leaf. DMesh::delta
@@ -97,12 +104,13 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
             if (hL) { link = left; continue; }
             if (hR) { link = right; continue; }
         } else {
-            uint2 lf = sc.mleaves[-1 - link];
-            for (uint32_t i = 0; i < lf.y; i++) {
-                uint32_t g = lf.x + i;
+            uint32_t g = leaf_first(link);
+            for (bool last = (link == LINK_EMPTY); !last; g++) {
                 const float4* q = sc.tri + 4 * (size_t)g;
+                float4 q2 = q[2];
+                last = __float_as_uint(q2.w) != 0u;
                 float t, w0, w1, w2;
-                if (tri_test(r, q[0], q[1], q[2], q[3], t, w0, w1, w2) && t < bestT) {
+                if (tri_test(r, q[0], q[1], q2, q[3], t, w0, w1, w2) && t < bestT) {
                     found = true; bestT = t; bestG = g; bw0 = w0; bw1 = w1; bw2 = w2;
                 }
             }
@@ -138,11 +146,13 @@ RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound
             if (hL) { link = left; continue; }
             if (hR) { link = right; continue; }
         } else {
-            uint2 lf = sc.mleaves[-1 - link];
-            for (uint32_t i = 0; i < lf.y; i++) {
-                const float4* q = sc.tri + 4 * (size_t)(lf.x + i);
+            uint32_t g = leaf_first(link);
+            for (bool last = (link == LINK_EMPTY); !last; g++) {
+                const float4* q = sc.tri + 4 * (size_t)g;
+                float4 q2 = q[2];
+                last = __float_as_uint(q2.w) != 0u;
                 float t, w0, w1, w2;
-                if (tri_test(r, q[0], q[1], q[2], q[3], t, w0, w1, w2) && t <= bound) return true;
+                if (tri_test(r, q[0], q[1], q2, q[3], t, w0, w1, w2) && t <= bound) return true;
             }
         }
         if (sp == sp0) break;
@@ -556,10 +566,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
  * (one wave-aggregated atomicAdd, lanes ranked with a ballot), and each lane runs a small state
  * machine -- top level (ST_TOP) or inside one mesh tree (ST_MESH) -- whose per-lane stack lives in LDS.
  * The traversal semantics are those of shadow_walk()/mesh_any() above (mode 0 / mode 1). */
+#define TRI_NONE 0xFFFFFFFFu
 #define ST_IDLE 0
 #define ST_TOP 1
 #define ST_MESH 2
-#define LINK_NONE ((int)0x80000000)
 #define RT_REFILL_MIN 8       /* refill once this many lanes are idle */
 #define RT_NODE_STEPS 16      /* node-phase steps between two refill checks */
 #define RT_TRI_STEPS 4        /* triangle-phase steps per round */
@@ -575,7 +585,7 @@ struct ShadowLane {
     uint32_t top_pos, top_end;
     int leaf_open;
     int link, msp;      /* mesh cursor and stack pointer */
-    uint32_t tri_pos, tri_end;
+    uint32_t tri_pos;   /* next triangle record of the leaf being tested, TRI_NONE if none */
 };
 
 RT_DEV void shadow_restart(const DScene& sc, ShadowLane& s, int mode, int limit) {
@@ -610,7 +620,7 @@ RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int st
             } else {
                 DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
                 s.slack = s.mode == 0 ? prune_slack(s.r, m.delta) : INFINITY;
-                s.link = m.root; s.msp = sc.top_cap; s.tri_pos = s.tri_end = 0;
+                s.link = m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
                 s.st = ST_MESH;
                 return;
             }
@@ -657,8 +667,8 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
         bool hR = slab(s.r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
         int left = __float_as_int(d.x), right = __float_as_int(d.y);
         bool nearLeft = tL <= tR;
-        hL = hL && !beyond(tL, s.slack, s.bound);
-        hR = hR && !beyond(tR, s.slack, s.bound);
+        hL = hL && !beyond(tL, s.slack, s.bound) && left != LINK_EMPTY;
+        hR = hR && !beyond(tR, s.slack, s.bound) && right != LINK_EMPTY;
         if (hL && hR) {
             stk[lds_index(s.msp++, stride)] = nearLeft ? right : left;
             link = nearLeft ? left : right;
@@ -668,36 +678,71 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
         else link = LINK_NONE;
     }
     if (link < 0 && link != LINK_NONE) {
-        uint2 lf = sc.mleaves[-1 - link];
-        s.tri_pos = lf.x; s.tri_end = lf.x + lf.y;
+        if (link != LINK_EMPTY) s.tri_pos = leaf_first(link);
         link = LINK_NONE;
     }
     s.link = link;
 }
 RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     const float4* q = sc.tri + 4 * (size_t)s.tri_pos;
-    s.tri_pos++;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    s.tri_pos = __float_as_uint(q2.w) != 0u ? TRI_NONE : s.tri_pos + 1;
     if (tri_surely_missed(s.r, q0, q1, q2, q3)) return;
     float t, w0, w1, w2;
     if (tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
 
+/* Scene::sampleSphereLight's sample position + Scene::isInShadow's ray (Scene.h:115-126,161-164) for
+ * every (record, light, sample), at full lane utilisation, 32 bytes per ray: (origin, lightDistance)
+ * (direction, -). The persistent kernel's refill then is two coalesced loads. */
+__global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
+                                                      const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
+                                                      float4* __restrict__ rays) {
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    if (idx >= total) return;
+    uint32_t key = (uint32_t)(idx / (unsigned)S);
+    uint32_t i = (uint32_t)(idx % (unsigned)S);
+    uint32_t rec = key / (uint32_t)sc.n_lights, li = key % (uint32_t)sc.n_lights;
+    const float4* q = reinterpret_cast<const float4*>(drec + rec);
+    float4 q0 = q[0], q3 = q[3];
+    F3 P = f3(q0.x, q0.y, q0.z);
+    DLight L = sc.lights[li];
+    F3 lp = f3(L.pos[0], L.pos[1], L.pos[2]);
+    if (fr.shadow_mode == 0) {
+        uint32_t pixel = __float_as_uint(q3.z), sample = __float_as_uint(q3.w);
+        unsigned long long code = dcode[rec];
+        uint32_t ky = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 0) % 360u;   /* randY first, Scene.h:115 */
+        uint32_t kx = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 1) % 360u;
+        double sinY = sc.sincos[ky], cosY = sc.sincos[360 + ky];
+        double sinX = sc.sincos[kx], cosX = sc.sincos[360 + kx];
+        float p1 = (float)(-sinY), p2 = (float)cosY;                                 /* Scene.h:119 */
+        float p0 = (float)(-sinX * (double)p2);                                      /* Scene.h:121 */
+        p2 = (float)(cosX * (double)p2);                                             /* Scene.h:122 */
+        lp = add(lp, mul(L.radius, f3(p0, p1, p2)));                                 /* Scene.h:124-126 */
+    }
+    F3 dir = sub(lp, P);                                                             /* Scene.h:161-164 */
+    float lightDistance = len(dir);
+    dir = normalized(dir);
+    F3 o = add(P, mul(0.001f, dir));
+    F3 d = normalized(dir);                                                          /* Line.h:15 */
+    rays[2 * idx] = make_float4(o.x, o.y, o.z, lightDistance);
+    rays[2 * idx + 1] = make_float4(d.x, d.y, d.z, 0.f);
+}
+
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
-                                                     const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
-                                                     uint32_t* cnt, Counters* ctr, unsigned long long* next, int count_steps) {
+__global__ void __launch_bounds__(RT_BLOCK, 6) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
+                                                        uint32_t* cnt, Counters* ctr, unsigned long long* next, int count_steps) {
     extern __shared__ int s_stack[];
     unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0;
     int* stk = s_stack + threadIdx.x;
-    const int stride = blockDim.x;
-    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    constexpr int stride = RT_BLOCK;        /* the host always launches RT_BLOCK-lane blocks */
     const int lane = __lane_id();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     ShadowLane s;
     s.st = ST_IDLE;
-    s.tri_pos = s.tri_end = 0;
+    s.tri_pos = TRI_NONE;
     bool exhausted = false;
     unsigned long long traced = 0;      /* lane 0 only */
     for (;;) {
@@ -712,30 +757,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const
             unsigned long long idx = base + __popcll(idle & lt);
             if (s.st == ST_IDLE && idx < total) {
                 s.key = (uint32_t)(idx / (unsigned)S);
-                uint32_t i = (uint32_t)(idx % (unsigned)S);
-                uint32_t rec = s.key / (uint32_t)sc.n_lights, li = s.key % (uint32_t)sc.n_lights;
-                const float4* q = reinterpret_cast<const float4*>(drec + rec);
-                float4 q0 = q[0], q3 = q[3];
-                F3 P = f3(q0.x, q0.y, q0.z);
-                DLight L = sc.lights[li];
-                F3 lp = f3(L.pos[0], L.pos[1], L.pos[2]);
-                if (fr.shadow_mode == 0) {
-                    uint32_t pixel = __float_as_uint(q3.z), sample = __float_as_uint(q3.w);
-                    unsigned long long code = dcode[rec];
-                    uint32_t ky = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 0) % 360u;   /* randY first, Scene.h:115 */
-                    uint32_t kx = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 1) % 360u;
-                    double sinY = sc.sincos[ky], cosY = sc.sincos[360 + ky];
-                    double sinX = sc.sincos[kx], cosX = sc.sincos[360 + kx];
-                    float p1 = (float)(-sinY), p2 = (float)cosY;                                 /* Scene.h:119 */
-                    float p0 = (float)(-sinX * (double)p2);                                      /* Scene.h:121 */
-                    p2 = (float)(cosX * (double)p2);                                             /* Scene.h:122 */
-                    lp = add(lp, mul(L.radius, f3(p0, p1, p2)));                                 /* Scene.h:124-126 */
-                }
-                F3 dir = sub(lp, P);                                                             /* Scene.h:161-164 */
-                s.lightDistance = len(dir);
-                dir = normalized(dir);
-                s.r = make_ray(add(P, mul(0.001f, dir)), dir);
-                s.tri_pos = s.tri_end = 0;
+                float4 ro = rays[2 * idx], rd = rays[2 * idx + 1];
+                s.lightDistance = ro.w;
+                s.r.o = f3(ro.x, ro.y, ro.z);
+                s.r.d = f3(rd.x, rd.y, rd.z);
+                s.r.inv = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);                 /* AccelerationStruct.cpp:19 */
+                s.tri_pos = TRI_NONE;
                 shadow_restart(sc, s, 0, 0);
             }
         }
@@ -747,8 +774,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const
         /* node phase */
 #pragma unroll 1
         for (int k = 0; k < RT_NODE_STEPS; k++) {
-            bool walking = s.st == ST_MESH && !(s.tri_pos < s.tri_end);
-            bool waiting = s.st == ST_MESH && (s.tri_pos < s.tri_end);
+            bool walking = s.st == ST_MESH && s.tri_pos == TRI_NONE;
+            bool waiting = s.st == ST_MESH && s.tri_pos != TRI_NONE;
             unsigned long long mw = __ballot(walking), mt = __ballot(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
             if (count_steps) { c_iter++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
@@ -757,7 +784,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, FrameD fr, const
         /* triangle phase */
 #pragma unroll 1
         for (int k = 0; k < RT_TRI_STEPS; k++) {
-            bool pending = s.st == ST_MESH && (s.tri_pos < s.tri_end);
+            bool pending = s.st == ST_MESH && s.tri_pos != TRI_NONE;
             if (__ballot(pending) == 0ull) break;
             if (count_steps) { c_iter++; if (pending) c_tri++; }
             if (pending) shadow_tri_step(sc, s, cnt);

@@ -8,8 +8,9 @@
  *            unit normal, area, plane D precomputed exactly as Triangle.h:28-33,58)
  *   tri_ids  uint4 per triangle (3 global vertex ids, index into Mesh::triangles)
  *   normals  3 floats per vertex
- *   mnodes   64-byte inner nodes of all mesh trees, child links global
- *   mleaves  (first,count) ranges into tri
+ *   mnodes   64-byte inner nodes of all mesh trees; a child link is a global node index, or
+ *            -2-first for a leaf whose triangle records start at `first` (the last record of a
+ *            leaf is flagged), or -1 for an empty leaf: no leaf table is read during traversal
  *   tnodes / tleaves / titems   top-level tree over object ordinals
  *   squares (64 B), spheres (32 B), materials (64 B), lights (32 B), sin/cos table
  * Per frame: int64 fixed-point accumulators (3 per pixel), prim ids, a LIFO stack of
@@ -52,7 +53,7 @@ struct rt_ctx {
     std::vector<TileD> tiles;
     unsigned long long queued_samples = 0;
 
-    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf;
+    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays;
     uint32_t batch = 1u << 20;
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 32;
@@ -241,17 +242,26 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         /* 3. shadow + Phong for the diffuse records of this batch */
         if (n_diff && L > 0) {
             HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
-            /* persistent waves: enough 64-lane blocks to fill the chip, never more than the work */
-            unsigned long long threads = (unsigned long long)n_diff * L * S;
-            unsigned long long blocks = std::min<unsigned long long>((threads + RT_BLOCK - 1) / RT_BLOCK, (unsigned long long)c->persistent_blocks);
-            HIP_TRY(c, hipMemsetAsync(&d_ctr->work, 0, sizeof(unsigned long long), c->stream));
-            EventPair* e2 = next_event(c, 1);
-            if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
-            HIP_TRY(c, hipEventRecord(e2->a, c->stream));
-            hipLaunchKernelGGL(k_shadow, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds, c->stream, c->sc, c->fr,
-                               static_cast<const DiffuseRec*>(c->drec.p), static_cast<const unsigned long long*>(c->dcode.p), n_diff, S,
-                               static_cast<uint32_t*>(c->cnt.p), d_ctr, &d_ctr->work, c->count_steps ? 1 : 0);
-            HIP_TRY(c, hipEventRecord(e2->b, c->stream));
+            /* the records are processed in chunks so that the 32-byte ray buffer stays below ~2 GiB */
+            const unsigned long long per_rec = (unsigned long long)L * S;
+            const uint32_t chunk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(n_diff, (64ull << 20) / per_rec));
+            if ((rc = ensure(c, c->srays, (size_t)chunk * per_rec * 2 * sizeof(float4)))) return rc;
+            for (uint32_t r0 = 0; r0 < n_diff; r0 += chunk) {
+                const uint32_t nr = std::min(chunk, n_diff - r0);
+                const unsigned long long threads = (unsigned long long)nr * per_rec;
+                /* persistent waves: enough 64-lane blocks to fill the chip, never more than the work */
+                const unsigned long long blocks = std::min<unsigned long long>((threads + RT_BLOCK - 1) / RT_BLOCK, (unsigned long long)c->persistent_blocks);
+                HIP_TRY(c, hipMemsetAsync(&d_ctr->work, 0, sizeof(unsigned long long), c->stream));
+                hipLaunchKernelGGL(k_shadow_setup, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->sc, c->fr,
+                                   static_cast<const DiffuseRec*>(c->drec.p) + r0, static_cast<const unsigned long long*>(c->dcode.p) + r0, nr, S,
+                                   static_cast<float4*>(c->srays.p));
+                EventPair* e2 = next_event(c, 1);
+                if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+                HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                hipLaunchKernelGGL(k_shadow, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds, c->stream, c->sc, static_cast<const float4*>(c->srays.p),
+                                   threads, S, static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L, d_ctr, &d_ctr->work, c->count_steps ? 1 : 0);
+                HIP_TRY(c, hipEventRecord(e2->b, c->stream));
+            }
         }
         if (n_diff) {
             if (L == 0) HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, 256, c->stream));
@@ -382,7 +392,7 @@ void rt_shutdown(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
-    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf}) release(*b);
+    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf, &c->srays}) release(*b);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     for (EventPair& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     (void)hipEventDestroy(c->ev_frame_a);
@@ -404,7 +414,6 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     std::vector<float4> tri((size_t)d->n_tris * 4);
     std::vector<uint4> ids((size_t)d->n_tris);
     std::vector<rt_bvh_node> nodes(d->mesh_nodes, d->mesh_nodes + d->n_mesh_nodes);
-    std::vector<uint2> leaves((size_t)d->n_mesh_leaves);
     std::vector<DMesh> meshes((size_t)d->n_meshes);
     int max_mesh_depth = 0;
     for (int mi = 0; mi < d->n_meshes; mi++) {
@@ -435,15 +444,22 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
             tri[4 * g + 3] = make_float4(n.x, n.y, n.z, 0.f);
             ids[g] = make_uint4((uint32_t)(m.vert_first + iv[0]), (uint32_t)(m.vert_first + iv[1]), (uint32_t)(m.vert_first + iv[2]), t);
         }
-        auto glob = [&](int32_t link) { return link >= 0 ? (int32_t)(link + m.node_first) : (int32_t)(-1 - ((-1 - link) + m.leaf_first)); };
+        auto glob = [&](int32_t link) {
+            if (link >= 0) return (int32_t)(link + m.node_first);
+            const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + (-1 - link)];
+            return lf.count == 0 ? (int32_t)-1 : (int32_t)(-2 - (int64_t)(lf.first + m.tri_first));
+        };
         for (int64_t i = 0; i < m.node_count; i++) {
             rt_bvh_node& n = nodes[(size_t)(m.node_first + i)];
             n.left = glob(n.left);
             n.right = glob(n.right);
         }
-        for (int64_t i = 0; i < m.leaf_count; i++) {
+        for (int64_t i = 0; i < m.leaf_count; i++) {           /* flag the last triangle record of every leaf */
             const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + i];
-            leaves[(size_t)(m.leaf_first + i)] = make_uint2((uint32_t)(lf.first + m.tri_first), lf.count);
+            if (lf.count) {
+                uint32_t one = 1u;
+                memcpy(&tri[4 * (size_t)(m.tri_first + lf.first + lf.count - 1) + 2].w, &one, 4);
+            }
         }
         meshes[mi].root = glob(m.root);
         meshes[mi].material = m.material;
@@ -514,7 +530,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     const rt_bvh_node* dn = nullptr;
     const rt_bvh_node* dtn = nullptr;
     if ((rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
-        (rc = upload(c, nodes, &dn)) || (rc = upload(c, leaves, &sc.mleaves)) || (rc = upload(c, meshes, &sc.meshes)) ||
+        (rc = upload(c, nodes, &dn)) || (rc = upload(c, meshes, &sc.meshes)) ||
         (rc = upload(c, tnodes, &dtn)) || (rc = upload(c, tleaves, &sc.tleaves)) || (rc = upload(c, titems, &sc.titems)) ||
         (rc = upload(c, squares, &sc.squares)) || (rc = upload(c, spheres, &sc.spheres)) || (rc = upload(c, mats, &sc.mats)) ||
         (rc = upload(c, lights, &sc.lights)) || (rc = upload(c, sincos, &sc.sincos))) {
