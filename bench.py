@@ -173,6 +173,7 @@ def main():
                                    f"(35 samples/light), depth {args.depth}, mesh BVH depth {args.mesh_depth}, counter RNG",
                        "tiles": "32x32 round-robin over ranks", "parallelism": f"tile-sharded x{world}",
                        "rays_primary": prim, "rays_secondary": sec, "rays_shadow": shad,
+                       "kernel_ms_per_step": {"k_shadow": round(ms_shadow / args.steps, 2), "k_closest": round(ms_closest / args.steps, 2)},
                        "scene_build_s": round(t_build, 2), "upload_s": round(t_upload, 2), "frame_checksum": checksum},
             "roofline": roof, "cpu_baseline": cpu,
         }

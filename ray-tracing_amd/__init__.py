@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "librtgpu.so")
+LIB_PATH = os.environ.get("RT_LIB", os.path.join(_HERE, "librtgpu.so"))   # RT_LIB: developer A/B knob
 DEFAULT_ASSET_DIR = os.path.join(ROOT, "tests", "golden", "models")
 
 RT_OK = 0

@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
 
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
-__global__ void __launch_bounds__(RT_BLOCK, 6) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
                                                         uint32_t* cnt, Counters* ctr, unsigned long long* next, int count_steps) {
     extern __shared__ int s_stack[];
     unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0;
