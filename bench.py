@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PER_RAY_FILE = os.path.join(ROOT, "profiles", "c5_per_ray.json")
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+CHECKSUM_FILE = os.path.join(ROOT, "profiles", "c5_checksum.json")   # frame checksums of the plain reference-order traversal
 
 
 def algorithmic_bytes_per_ray(n_node, n_tri):
@@ -147,6 +148,13 @@ def main():
                        "shadow_tris": ost.sh_tri_tests / max(ost.rays_shadow, 1),
                        "closest_nodes": (ost.node_visits - ost.sh_node_visits) / max(ost.rays_primary + ost.rays_secondary, 1),
                        "closest_tris": (ost.tri_tests - ost.sh_tri_tests) / max(ost.rays_primary + ost.rays_secondary, 1)}
+        checksum_ok = None
+        try:
+            want = json.load(open(CHECKSUM_FILE)).get(f"{name}/d{args.mesh_depth}/{W}x{H}x{args.spp}/depth{args.depth}")
+            if want is not None:
+                checksum_ok = bool(want == checksum)
+        except Exception:
+            pass
         roof = None
         if per_ray and n_shadow:
             bpr = algorithmic_bytes_per_ray(per_ray["shadow_nodes"], per_ray["shadow_tris"])
@@ -174,7 +182,7 @@ def main():
                        "tiles": "32x32 round-robin over ranks", "parallelism": f"tile-sharded x{world}",
                        "rays_primary": prim, "rays_secondary": sec, "rays_shadow": shad,
                        "kernel_ms_per_step": {"k_shadow": round(ms_shadow / args.steps, 2), "k_closest": round(ms_closest / args.steps, 2)},
-                       "scene_build_s": round(t_build, 2), "upload_s": round(t_upload, 2), "frame_checksum": checksum},
+                       "scene_build_s": round(t_build, 2), "upload_s": round(t_upload, 2), "frame_checksum": checksum, "frame_checksum_matches_reference_order_traversal": checksum_ok},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -140,21 +140,6 @@ RT_DEV bool tri_test(const Ray& r, float4 q0, float4 q1, float4 q2, float4 q3, f
     return true;
 }
 
-/* Cheap conservative pre-test for tri_test(): true only when the exact test is certain to reject.
- * The exact test rejects when u0+u1+u2 > 1.00001 (Triangle.h:105); with 1-ulp square roots the sum
- * of the three sub-triangle areas is known to ~1e-6 relative, so "> 1.001 * area" cannot disagree.
- * NaNs compare false and fall through to the exact test. */
-RT_DEV bool tri_surely_missed(const Ray& r, float4 q0, float4 q1, float4 q2, float4 q3) {
-    F3 c0 = f3(q0.x, q0.y, q0.z), c1 = f3(q1.x, q1.y, q1.z), c2 = f3(q2.x, q2.y, q2.z), n = f3(q3.x, q3.y, q3.z);
-    float dn = dot(r.d, n);
-    float t = (q0.w - dot(r.o, n)) * __builtin_amdgcn_rcpf(dn);
-    F3 P = add(r.o, mul(t, r.d));
-    float l0 = __builtin_amdgcn_sqrtf(sqlen(cross(sub(c2, c1), sub(P, c1))));
-    float l1 = __builtin_amdgcn_sqrtf(sqlen(cross(sub(c0, c2), sub(P, c2))));
-    float l2 = __builtin_amdgcn_sqrtf(sqlen(cross(sub(c1, c0), sub(P, c0))));
-    return (l0 + l1 + l2) * 0.5f > q1.w * 1.001f;
-}
-
 /* Sphere::intersect, Sphere.h:86-146. */
 RT_DEV bool sphere_test(const Ray& r, float4 s, float& t_out, F3& n_out) {
     F3 c = f3(s.x, s.y, s.z);

@@ -687,7 +687,6 @@ RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     const float4* q = sc.tri + 4 * (size_t)s.tri_pos;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     s.tri_pos = __float_as_uint(q2.w) != 0u ? TRI_NONE : s.tri_pos + 1;
-    if (tri_surely_missed(s.r, q0, q1, q2, q3)) return;
     float t, w0, w1, w2;
     if (tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
