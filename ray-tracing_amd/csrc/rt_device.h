@@ -127,14 +127,16 @@ RT_DEV bool tri_test(const Ray& r, float4 q0, float4 q1, float4 q2, float4 q3, f
     if (dn == 0) return false;                                   /* Triangle.h:49-53 */
     float t = (D - dot(r.o, n)) / dn;                            /* Triangle.h:59 */
     F3 P = add(r.o, mul(t, r.d));                                /* Triangle.h:61 */
-    F3 cd = normalized(sub(P, r.o));                             /* Triangle.h:94-95 */
-    if (dot(cd, r.d) < 0) return false;                          /* Triangle.h:96 */
+    /* The reference tests "in front" (Triangle.h:94-96) before the barycentric sum (Triangle.h:101-107);
+     * both must pass and neither has side effects, so the one that rejects most goes first. */
     /* Triangle.h:65-84: (|C| / 2.) / area in double, narrowed; equal to the float quotient below */
     float u0 = (len(cross(sub(c2, c1), sub(P, c1))) * 0.5f) / area;
     float u1 = (len(cross(sub(c0, c2), sub(P, c2))) * 0.5f) / area;
     float u2 = (len(cross(sub(c1, c0), sub(P, c0))) * 0.5f) / area;
     float sum = u0 + u1 + u2;
     if ((double)sum < 0.9999 || (double)sum > 1.00001) return false;   /* Triangle.h:105 */
+    F3 cd = normalized(sub(P, r.o));                             /* Triangle.h:94-95 */
+    if (dot(cd, r.d) < 0) return false;                          /* Triangle.h:96 */
     t_out = len(sub(r.o, P));                                    /* Triangle.h:110 */
     w0 = u0; w1 = u1; w2 = u2;
     return true;

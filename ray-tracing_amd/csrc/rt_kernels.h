@@ -50,10 +50,10 @@ struct HitD { int exists; float t; int obj; int tri; F3 n; F3 pos; float u, v; i
 
 RT_DEV int lds_index(int k, int stride) { return k * stride; }
 
-/* Child links of the mesh trees on the device: >= 0 inner node; LINK_EMPTY a leaf without triangles;
- * <= -2 a leaf whose triangles start at record -2-link (the last record of a leaf carries a flag in
- * word 2.w), so that reaching a leaf costs no extra fetch; LINK_NONE = no link. */
-#define LINK_EMPTY (-1)
+/* Child links of the mesh trees on the device: >= 0 inner node; <= -2 a leaf whose triangles start at
+ * record -2-link (the last record of a leaf carries a flag in word 2.w), so that reaching a leaf costs
+ * no extra fetch; a leaf without triangles points at one shared all-zero record (normal 0 => d.n == 0
+ * => Triangle::isParallelTo rejects it); LINK_NONE = no link. */
 #define LINK_NONE ((int)0x80000000)
 RT_DEV uint32_t leaf_first(int link) { return (uint32_t)(-2 - link); }
 
@@ -105,7 +105,7 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
             if (hR) { link = right; continue; }
         } else {
             uint32_t g = leaf_first(link);
-            for (bool last = (link == LINK_EMPTY); !last; g++) {
+            for (bool last = false; !last; g++) {
                 const float4* q = sc.tri + 4 * (size_t)g;
                 float4 q2 = q[2];
                 last = __float_as_uint(q2.w) != 0u;
@@ -147,7 +147,7 @@ RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound
             if (hR) { link = right; continue; }
         } else {
             uint32_t g = leaf_first(link);
-            for (bool last = (link == LINK_EMPTY); !last; g++) {
+            for (bool last = false; !last; g++) {
                 const float4* q = sc.tri + 4 * (size_t)g;
                 float4 q2 = q[2];
                 last = __float_as_uint(q2.w) != 0u;
@@ -578,7 +578,7 @@ struct ShadowLane {
     Ray r;
     float bound;        /* lightDistance (mode 0) or just below FLT_MAX (mode 1) */
     float lightDistance;
-    float slack;        /* prune slack of the current mesh (inf in mode 1) */
+    float prune_t;      /* a child whose slab entry exceeds this cannot hold a hit at t <= bound (inf in mode 1) */
     uint32_t key;       /* record*n_lights + light */
     int st, mode, visited, limit;
     int tlink, tsp;     /* top-level cursor and stack pointer */
@@ -619,7 +619,9 @@ RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int st
                 if (sphere_test(s.r, q[0], t, n) && t <= s.bound) { shadow_on_hit(sc, s, cnt); if (s.st == ST_IDLE) return; }
             } else {
                 DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
-                s.slack = s.mode == 0 ? prune_slack(s.r, m.delta) : INFINITY;
+                /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter > bound*1.00002 + slack is
+                 * still conservative and costs one compare per child */
+                s.prune_t = s.mode == 0 ? s.bound * 1.00002f + prune_slack(s.r, m.delta) : INFINITY;
                 s.link = m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
                 s.st = ST_MESH;
                 return;
@@ -667,8 +669,8 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
         bool hR = slab(s.r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
         int left = __float_as_int(d.x), right = __float_as_int(d.y);
         bool nearLeft = tL <= tR;
-        hL = hL && !beyond(tL, s.slack, s.bound) && left != LINK_EMPTY;
-        hR = hR && !beyond(tR, s.slack, s.bound) && right != LINK_EMPTY;
+        hL = hL && !(tL > s.prune_t);
+        hR = hR && !(tR > s.prune_t);
         if (hL && hR) {
             stk[lds_index(s.msp++, stride)] = nearLeft ? right : left;
             link = nearLeft ? left : right;
@@ -678,7 +680,7 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
         else link = LINK_NONE;
     }
     if (link < 0 && link != LINK_NONE) {
-        if (link != LINK_EMPTY) s.tri_pos = leaf_first(link);
+        s.tri_pos = leaf_first(link);
         link = LINK_NONE;
     }
     s.link = link;

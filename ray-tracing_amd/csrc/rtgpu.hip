@@ -10,7 +10,7 @@
  *   normals  3 floats per vertex
  *   mnodes   64-byte inner nodes of all mesh trees; a child link is a global node index, or
  *            -2-first for a leaf whose triangle records start at `first` (the last record of a
- *            leaf is flagged), or -1 for an empty leaf: no leaf table is read during traversal
+ *            leaf is flagged; empty leaves share one never-hit record): no leaf table is read
  *   tnodes / tleaves / titems   top-level tree over object ordinals
  *   squares (64 B), spheres (32 B), materials (64 B), lights (32 B), sin/cos table
  * Per frame: int64 fixed-point accumulators (3 per pixel), prim ids, a LIFO stack of
@@ -411,7 +411,11 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     DScene sc{};
 
     /* triangles in leaf order with the per-test quantities of Triangle.h precomputed */
-    std::vector<float4> tri((size_t)d->n_tris * 4);
+    std::vector<float4> tri(((size_t)d->n_tris + 1) * 4, make_float4(0.f, 0.f, 0.f, 0.f));   /* +1: the record empty leaves point at */
+    {
+        uint32_t one = 1u;
+        memcpy(&tri[4 * (size_t)d->n_tris + 2].w, &one, 4);
+    }
     std::vector<uint4> ids((size_t)d->n_tris);
     std::vector<rt_bvh_node> nodes(d->mesh_nodes, d->mesh_nodes + d->n_mesh_nodes);
     std::vector<DMesh> meshes((size_t)d->n_meshes);
@@ -447,7 +451,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         auto glob = [&](int32_t link) {
             if (link >= 0) return (int32_t)(link + m.node_first);
             const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + (-1 - link)];
-            return lf.count == 0 ? (int32_t)-1 : (int32_t)(-2 - (int64_t)(lf.first + m.tri_first));
+            return lf.count == 0 ? (int32_t)(-2 - d->n_tris) : (int32_t)(-2 - (int64_t)(lf.first + m.tri_first));
         };
         for (int64_t i = 0; i < m.node_count; i++) {
             rt_bvh_node& n = nodes[(size_t)(m.node_first + i)];
