@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __
     bool exhausted = false;
     unsigned long long traced = 0;      /* lane 0 only */
     for (;;) {
-        unsigned long long idle = __ballot(s.st == ST_IDLE);
+        unsigned long long idle = __builtin_amdgcn_ballot_w64(s.st == ST_IDLE);
         if (!exhausted && (__popcll(idle) >= RT_REFILL_MIN)) {
             uint32_t n = __popcll(idle);
             unsigned long long base = 0;
@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __
                 shadow_restart(sc, s, 0, 0);
             }
         }
-        if (__ballot(s.st != ST_IDLE) == 0ull) {
+        if (__builtin_amdgcn_ballot_w64(s.st != ST_IDLE) == 0ull) {
             if (exhausted) break;
             continue;
         }
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __
         for (int k = 0; k < RT_NODE_STEPS; k++) {
             bool walking = s.st == ST_MESH && s.tri_pos == TRI_NONE;
             bool waiting = s.st == ST_MESH && s.tri_pos != TRI_NONE;
-            unsigned long long mw = __ballot(walking), mt = __ballot(waiting);
+            unsigned long long mw = __builtin_amdgcn_ballot_w64(walking), mt = __builtin_amdgcn_ballot_w64(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
             if (count_steps) { c_iter++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
             if (walking) shadow_node_step(sc, s, stk, stride);
@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __
 #pragma unroll 1
         for (int k = 0; k < RT_TRI_STEPS; k++) {
             bool pending = s.st == ST_MESH && s.tri_pos != TRI_NONE;
-            if (__ballot(pending) == 0ull) break;
+            if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
             if (count_steps) { c_iter++; if (pending) c_tri++; }
             if (pending) shadow_tri_step(sc, s, cnt);
         }

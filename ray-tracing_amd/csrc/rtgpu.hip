@@ -27,6 +27,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <utility>
 
 namespace {
 
@@ -56,7 +57,7 @@ struct rt_ctx {
     DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays;
     uint32_t batch = 1u << 20;
     bool debug = false, count_steps = false;
-    int persistent_blocks = 256 * 32;
+    int persistent_blocks = 256 * 16;
     size_t stack_cap = 0;       /* states */
     Counters* h_ctr = nullptr;  /* pinned */
     rt_stats stats{};
@@ -297,6 +298,27 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
     return RT_OK;
 }
 
+/* The links must form a tree no deeper than declared: the device stacks are sized by the declared depth
+ * and the kernels loop until the links run out, so a cycle or a shared child would never end.
+ * (Links are already known to be in range.) Returns what is wrong, or nullptr. */
+const char* tree_defect(const rt_bvh_node* nodes, int64_t n_nodes, int32_t root, int32_t depth) {
+    if (depth < 0) return "negative tree depth";
+    if (root < 0) return nullptr;                       /* a single leaf */
+    std::vector<uint8_t> seen((size_t)n_nodes, 0);
+    std::vector<std::pair<int32_t, int32_t>> todo(1, std::make_pair(root, 0));
+    while (!todo.empty()) {
+        const std::pair<int32_t, int32_t> cur = todo.back();
+        todo.pop_back();
+        if (seen[(size_t)cur.first]) return "a node has two parents or lies on a cycle";
+        seen[(size_t)cur.first] = 1;
+        if (cur.second >= depth) return "tree deeper than its declared depth";
+        const rt_bvh_node& n = nodes[cur.first];
+        if (n.left >= 0) todo.push_back(std::make_pair(n.left, cur.second + 1));
+        if (n.right >= 0) todo.push_back(std::make_pair(n.right, cur.second + 1));
+    }
+    return nullptr;
+}
+
 int check_desc(rt_ctx* c, const rt_scene_desc* d) {
     if (d->n_lights > RT_MAX_LIGHTS) return fail(c, RT_ERR_LIMIT, "more than %d lights", RT_MAX_LIGHTS);
     if (d->n_materials <= 0 && (d->n_squares + d->n_spheres + d->n_meshes) > 0) return fail(c, RT_ERR_ARG, "no materials");
@@ -309,6 +331,8 @@ int check_desc(rt_ctx* c, const rt_scene_desc* d) {
     for (int i = 0; i < d->n_top_nodes; i++)
         if (!link_ok(d->top_nodes[i].left, d->n_top_nodes, d->n_top_leaves) || !link_ok(d->top_nodes[i].right, d->n_top_nodes, d->n_top_leaves))
             return fail(c, RT_ERR_ARG, "top node %d: child link out of range", i);
+    if (n_obj > 0)
+        if (const char* why = tree_defect(d->top_nodes, d->n_top_nodes, d->top_root, d->top_depth)) return fail(c, RT_ERR_ARG, "top-level tree: %s", why);
     for (int i = 0; i < d->n_top_leaves; i++)
         if ((int64_t)d->top_leaves[i].first + d->top_leaves[i].count > d->n_top_items) return fail(c, RT_ERR_ARG, "top leaf %d out of range", i);
     for (int i = 0; i < d->n_top_items; i++)
@@ -332,6 +356,8 @@ int check_desc(rt_ctx* c, const rt_scene_desc* d) {
             const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + i];
             if ((int64_t)lf.first + lf.count > m.tri_count) return fail(c, RT_ERR_ARG, "mesh %d leaf %lld out of range", mi, (long long)i);
         }
+        if (const char* why = tree_defect(d->mesh_nodes + m.node_first, m.node_count, m.root, m.depth))
+            return fail(c, RT_ERR_ARG, "mesh %d: %s", mi, why);
         for (int64_t i = 0; i < m.tri_count; i++) {
             if (d->mesh_items[m.tri_first + i] >= (uint64_t)m.tri_count) return fail(c, RT_ERR_ARG, "mesh %d: item out of range", mi);
             for (int k = 0; k < 3; k++)
@@ -379,7 +405,7 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            c->persistent_blocks = prop.multiProcessorCount * 32;    /* 32 one-wave blocks per CU is the residency cap */
+            c->persistent_blocks = prop.multiProcessorCount * 16;    /* measured on C5: 16 one-wave blocks per CU (4 per SIMD) beat 12/14/18/20; more rays in flight thrash L1/L2 */
         const char* pb = getenv("RT_PERSISTENT_BLOCKS");
         if (pb && atoi(pb) > 0) c->persistent_blocks = atoi(pb);
     }

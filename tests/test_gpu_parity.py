@@ -264,5 +264,24 @@ def test_call_order_and_limits(rt):
         c.render_tile(0, 0, 0, 0)                        # empty tile is a no-op
         rgb, prim, st = c.download()
         assert st.rays == 0 and not rgb.any()
+        # a tree whose links loop, share a child or go deeper than declared is refused at upload
+        hs = rt.HostScene("mesh_cow", 3, 6)
+        dp = hs.desc                                     # one flattening; the library reads this copy
+        d = dp.contents
+        upload = lambda: c._check(c.L.rt_upload_scene(c.h, dp), "rt_upload_scene")
+        m = d.meshes[0]
+        node = d.mesh_nodes[m.node_first + m.root]
+        keep = node.left
+        assert keep >= 0
+        node.left = m.root                               # the root becomes its own child
+        with pytest.raises(rt.RtError, match="cycle"):
+            upload()
+        node.left = keep
+        deep = m.depth
+        m.depth = 2
+        with pytest.raises(rt.RtError, match="deeper"):
+            upload()
+        m.depth = deep
+        upload()                                         # restored: accepted again
     finally:
         c.close()
