@@ -167,8 +167,10 @@ def main():
                     traffic = json.load(open(TRAFFIC_FILE)).get("k_shadow_bytes_per_launch")
                 except Exception:
                     traffic = None
+            traffic_rate = round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None     # measured HBM-side GB/s
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_shadow",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_rate": traffic_rate,
+                    "traffic_frac": round(traffic_rate / HBM_PEAK_GBS, 4) if traffic_rate else None, "kernel": "k_shadow",
                     "avg_launch_ms": round(avg_ms, 3), "launches": n_shadow,
                     "bytes_per_ray": round(bpr, 1), "rays_per_launch": round(rays_per_launch, 1),
                     "closest_kernel_ms": round(ms_closest / max(n_closest, 1), 3)}
