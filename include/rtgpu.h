@@ -167,6 +167,10 @@ int rt_download_framebuffer(rt_ctx*, float* rgb, uint32_t* prim_id, rt_stats* st
 /* Same resolve, into DEVICE memory of the caller (img_w*img_h*3 floats), for RCCL gathers. */
 int rt_resolve_device(rt_ctx*, void* d_rgb);
 int rt_get_stats(rt_ctx*, rt_stats* stats);
+/* Diagnostic, no counterpart in the reference: 1 if the uploaded scene's shadow rays walk the 32-byte
+ * quantised copies of the mesh nodes (all mesh boxes finite and nested, as bounding boxes of triangle
+ * sets are), 0 if they walk the reference's nodes directly, negative on error. Results are identical. */
+int rt_uses_quantised_shadow_nodes(const rt_ctx*);
 
 /* Fine-grained seams, host arrays in and out:
  * Scene::computeIntersection (Scene.h:84-88) on n rays (origin, direction as given to Ray()). */

@@ -63,13 +63,22 @@ struct DMat {              /* 64 B */
     int32_t pad;
 };
 struct DLight { float pos[3]; float radius; float color[3]; float pad; };
-struct DMesh { int32_t root; int32_t material; float delta; int32_t pad; };   /* delta: see prune_slack() */
+struct DMesh {                 /* 48 B */
+    int32_t root;              /* link of the tree's root */
+    int32_t material;
+    float delta;               /* see prune_slack() */
+    float amax;                /* largest |coordinate| of the mesh's vertices */
+    float qmin[3], qstep[3];   /* frame of the 16-bit box planes in DScene::qnodes: plane = qmin + q*qstep */
+    int32_t pad[2];
+};
 
 struct DScene {
     const float4* tri;          /* 4 x float4 per triangle, leaf order: (c0,D) (c1,area) (c2,last-in-leaf flag) (n,-) */
     const uint4* tri_ids;       /* (v0, v1, v2 global vertex ids, index into Mesh::triangles), leaf order */
     const float* normals;       /* 3 per vertex */
     const float4* mnodes;       /* 4 x float4 per inner node; child links encoded as in rt_kernels.h (LINK_*) */
+    const uint4* qnodes;        /* shadow walk: the same nodes in 32 bytes, child boxes rounded outward to 16-bit planes */
+    const float4* lbox;         /* 2 x float4 per triangle slot: the reference box of the leaf that starts at this record */
     const DMesh* meshes;
     const float4* tnodes;
     const uint2* tleaves;
@@ -83,6 +92,7 @@ struct DScene {
     int32_t top_root;
     int32_t top_cap;            /* stack entries reserved for the top level */
     int32_t stack_cap;          /* total per-lane stack entries */
+    int32_t quant_ok;           /* all mesh boxes are finite and nested: the 32-byte shadow nodes may be used */
 };
 
 struct Ray { F3 o, d, inv; };

@@ -39,6 +39,8 @@ struct Counters {
     unsigned long long work;        /* next unclaimed shadow-ray index of the running k_shadow launch */
     unsigned long long pad2;
     unsigned long long sh_node_steps, sh_tri_steps, sh_other_steps, sh_loop_iters;   /* RT_COUNT=1 diagnostics */
+    unsigned long long sh_node_iters, sh_tri_iters, sh_top_iters, sh_top_lanes;
+    unsigned long long sh_clk_refill, sh_clk_top, sh_clk_node, sh_clk_tri;             /* wave clocks per section (s_memtime) */      /* wave iterations per phase; lanes entering the top-level step */
 };
 struct TileD { int32_t x0, y0, w, h; unsigned long long first; };
 struct CameraD { double pinv[16], mvinv[16]; float eye[3]; float pad; };
@@ -570,9 +572,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
 #define ST_IDLE 0
 #define ST_TOP 1
 #define ST_MESH 2
+#ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 8       /* refill once this many lanes are idle */
+#endif
+#ifndef RT_GRAB
+#define RT_GRAB 512u           /* rays a wave takes from the global counter at a time */
+#endif
+#ifndef RT_NODE_STEPS
 #define RT_NODE_STEPS 16      /* node-phase steps between two refill checks */
+#endif
+#ifndef RT_TRI_STEPS
 #define RT_TRI_STEPS 4        /* triangle-phase steps per round */
+#endif
 
 struct ShadowLane {
     Ray r;
@@ -585,7 +596,11 @@ struct ShadowLane {
     uint32_t top_pos, top_end;
     int leaf_open;
     int link, msp;      /* mesh cursor and stack pointer */
-    uint32_t tri_pos;   /* next triangle record of the leaf being tested, TRI_NONE if none */
+    uint32_t tri_pos;   /* next triangle record of the leaf being tested, TRI_NONE if none; quantised walk: bit 31
+                         * (TRI_NEW) = the leaf's own box is still to be tested */
+    /* quantised walk only, set when a mesh is entered: plane time = q*qa + qn (entry planes) / qf (exit planes) */
+    F3 qa, qn, qf;
+    uint32_t rot[3];    /* 16 where 1/d < 0: swaps the lo and hi halves of a packed plane pair */
 };
 
 RT_DEV void shadow_restart(const DScene& sc, ShadowLane& s, int mode, int limit) {
@@ -605,6 +620,8 @@ RT_DEV void shadow_on_hit(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     shadow_restart(sc, s, 1, s.visited);
 }
 /* top-level state machine: runs until the ray ends or enters a mesh tree */
+RT_DEV void quant_setup(ShadowLane& s, const DMesh& m);
+template <bool QUANT>
 RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int stride, uint32_t* cnt) {
     for (;;) {
         if (s.top_pos < s.top_end) {
@@ -623,6 +640,7 @@ RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int st
                  * still conservative and costs one compare per child */
                 s.prune_t = s.mode == 0 ? s.bound * 1.00002f + prune_slack(s.r, m.delta) : INFINITY;
                 s.link = m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
+                if (QUANT) quant_setup(s, m);
                 s.st = ST_MESH;
                 return;
             }
@@ -693,6 +711,102 @@ RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     if (tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
 
+
+/* ------------------------------------------------------------------ quantised shadow nodes
+ * A shadow query only asks whether SOME triangle the reference reaches is hit at t <= bound (see
+ * shadow_on_hit), so neither the visiting order nor the route to a leaf matters -- only which leaves
+ * the reference reaches. It reaches a leaf iff AABB::intersect passes for every box on the way down
+ * (AccelerationStruct.cpp:255-283). Those boxes are nested (each bounds a subset of its parent's
+ * triangles; checked at upload) and the slab arithmetic is monotone in the box planes -- a smaller
+ * box gives entry times that are no smaller and exit times that are no larger, and a NaN product only
+ * ever drops a constraint -- hence:  the leaf's own box passes  =>  every box above it passes.
+ * So the reference reaches exactly the leaves whose OWN box passes its test, and the boxes above the
+ * leaves may be replaced by anything that never loses such a leaf.
+ *
+ * k_shadow is bound by the vector L1's look-up rate (one 16-byte lane access per clock per CU when the
+ * lanes sit at unrelated nodes), i.e. by the number of 16-byte pieces a ray
+ * fetches. DScene::qnodes therefore holds the nodes in 32 bytes instead of 64: the child boxes rounded
+ * OUTWARD to 16-bit planes in the mesh's frame (quantise_mesh in rtgpu.hip), x|y|z of a box as
+ * lo | hi << 16. The test is conservative: one fma per plane, t = q*(qstep*inv) + ((qmin - o)*inv -/+
+ * slack), slack = 2e-6 * max(|o|,|mesh|) * |1/d| of that axis -- more than the rounding differences
+ * between this form on the padded planes and the reference's (plane - o)*inv on the true ones
+ * (below 1e-6 * M * |inv| in total). v_max3/v_min3 drop NaN operands, which only loosens the test.
+ * A leaf is then entered only if the reference's own test (slab()) passes on the leaf's reference
+ * box (DScene::lbox), and its triangles are tested exactly as before: bit-identical occlusion. */
+#define TRI_NEW 0x80000000u
+RT_DEV void quant_setup(ShadowLane& s, const DMesh& m) {
+    const Ray& r = s.r;
+    float M = 1.01f * fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fmaxf(fabsf(r.o.z), m.amax));
+    float ix = fabsf(r.inv.x), iy = fabsf(r.inv.y), iz = fabsf(r.inv.z);
+    /* an infinite 1/d gives NaN or +-inf plane times in both forms; its slack is irrelevant, 0 keeps the constants clean */
+    float ex = 2e-6f * M * (ix < INFINITY ? ix : 0.f), ey = 2e-6f * M * (iy < INFINITY ? iy : 0.f), ez = 2e-6f * M * (iz < INFINITY ? iz : 0.f);
+    s.qa = f3(m.qstep[0] * r.inv.x, m.qstep[1] * r.inv.y, m.qstep[2] * r.inv.z);
+    float bx = (m.qmin[0] - r.o.x) * r.inv.x, by = (m.qmin[1] - r.o.y) * r.inv.y, bz = (m.qmin[2] - r.o.z) * r.inv.z;
+    s.qn = f3(bx - ex, by - ey, bz - ez);
+    s.qf = f3(bx + ex, by + ey, bz + ez);
+    s.rot[0] = r.inv.x < 0.0f ? 16u : 0u;      /* a negative 1/d swaps the roles of the two planes (AccelerationStruct.cpp:22) */
+    s.rot[1] = r.inv.y < 0.0f ? 16u : 0u;
+    s.rot[2] = r.inv.z < 0.0f ? 16u : 0u;
+}
+/* conservative entry time of one quantised box (three packed plane pairs); hit = the slab is not empty within [0, lim] */
+RT_DEV float quant_entry(uint32_t wx, uint32_t wy, uint32_t wz, const ShadowLane& s, float lim, bool& hit) {
+    wx = __builtin_amdgcn_alignbit(wx, wx, s.rot[0]);
+    wy = __builtin_amdgcn_alignbit(wy, wy, s.rot[1]);
+    wz = __builtin_amdgcn_alignbit(wz, wz, s.rot[2]);
+    float a = __builtin_fmaf((float)(wx & 0xFFFFu), s.qa.x, s.qn.x), d = __builtin_fmaf((float)(wx >> 16), s.qa.x, s.qf.x);
+    float b = __builtin_fmaf((float)(wy & 0xFFFFu), s.qa.y, s.qn.y), e = __builtin_fmaf((float)(wy >> 16), s.qa.y, s.qf.y);
+    float c = __builtin_fmaf((float)(wz & 0xFFFFu), s.qa.z, s.qn.z), f = __builtin_fmaf((float)(wz >> 16), s.qa.z, s.qf.z);
+    float tMin = fmaxf(fmaxf(fmaxf(a, b), c), 0.0f);
+    float tMax = fminf(fminf(fminf(d, e), f), lim);
+    hit = tMin <= tMax;
+    return tMin;
+}
+RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, int* stk, int stride) {
+    int link = s.link;
+    if (link == LINK_NONE) {
+        if (s.msp == sc.top_cap) { s.st = ST_TOP; return; }        /* mesh done without a hit: next object of the leaf */
+        link = stk[lds_index(--s.msp, stride)];
+    }
+    if (link >= 0) {
+        const uint4* nd = sc.qnodes + 2 * (size_t)link;
+        uint4 a = nd[0], b = nd[1];
+        const float lim = fminf(100.0f, s.prune_t);                  /* tMax of AABB::intersect; beyond prune_t nothing can matter */
+        bool hL, hR;
+        float tL = quant_entry(a.x, a.y, a.z, s, lim, hL);
+        float tR = quant_entry(a.w, b.x, b.y, s, lim, hR);
+        int left = (int)b.z, right = (int)b.w;
+        bool nearLeft = tL <= tR;
+        if (hL && hR) {
+            stk[lds_index(s.msp++, stride)] = nearLeft ? right : left;
+            link = nearLeft ? left : right;
+        } else if (hL) link = left;
+        else if (hR) link = right;
+        else if (s.msp > sc.top_cap) link = stk[lds_index(--s.msp, stride)];
+        else link = LINK_NONE;
+    }
+    if (link < 0 && link != LINK_NONE) {
+        s.tri_pos = leaf_first(link) | TRI_NEW;
+        link = LINK_NONE;
+    }
+    s.link = link;
+}
+/* one triangle of a leaf of the quantised walk; the first one brings the reference's test of the leaf's own box along */
+RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
+    const uint32_t pos = s.tri_pos & ~TRI_NEW;
+    const float4* q = sc.tri + 4 * (size_t)pos;
+    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    bool reached = true;
+    if (s.tri_pos & TRI_NEW) {
+        const float4* bx = sc.lbox + 2 * (size_t)pos;
+        float4 b0 = bx[0], b1 = bx[1];
+        float tEnter;
+        reached = slab(s.r, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tEnter) && !(tEnter > s.prune_t);
+    }
+    s.tri_pos = (!reached || __float_as_uint(q2.w) != 0u) ? TRI_NONE : pos + 1;
+    float t, w0, w1, w2;
+    if (reached && tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
+}
+
 /* Scene::sampleSphereLight's sample position + Scene::isInShadow's ray (Scene.h:115-126,161-164) for
  * every (record, light, sample), at full lane utilisation, 32 bytes per ray: (origin, lightDistance)
  * (direction, -). The persistent kernel's refill then is two coalesced loads. */
@@ -733,10 +847,12 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
 
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
-                                                        uint32_t* cnt, Counters* ctr, unsigned long long* next, int count_steps) {
+template <bool QUANT, bool COUNT>      /* COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
+                                                        uint32_t* cnt, Counters* ctr, unsigned long long* next) {
+    constexpr bool count_steps = COUNT;
     extern __shared__ int s_stack[];
-    unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0;
+    unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0, c_wn = 0, c_wt = 0, c_wtop = 0, c_ltop = 0;
     int* stk = s_stack + threadIdx.x;
     constexpr int stride = RT_BLOCK;        /* the host always launches RT_BLOCK-lane blocks */
     const int lane = __lane_id();
@@ -744,18 +860,38 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __
     ShadowLane s;
     s.st = ST_IDLE;
     s.tri_pos = TRI_NONE;
-    bool exhausted = false;
+    bool exhausted = false;             /* the global counter has run out; the wave-local range may still hold rays */
+    unsigned long long wpos = 0, wend = 0;
     unsigned long long traced = 0;      /* lane 0 only */
+    unsigned long long k_refill = 0, k_top = 0, k_nodeph = 0, k_triph = 0, k_t0 = 0, k_t1;
     for (;;) {
+        if (count_steps) k_t0 = __builtin_readcyclecounter();
         unsigned long long idle = __builtin_amdgcn_ballot_w64(s.st == ST_IDLE);
-        if (!exhausted && (__popcll(idle) >= RT_REFILL_MIN)) {
-            uint32_t n = __popcll(idle);
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(next, (unsigned long long)n);
-            base = __shfl(base, 0);
-            if (base + n >= total) exhausted = true;
-            if (lane == 0 && base < total) traced += (base + n <= total) ? n : (total - base);
-            unsigned long long idx = base + __popcll(idle & lt);
+        if ((!exhausted || wpos < wend) && (__popcll(idle) >= RT_REFILL_MIN)) {
+            /* ray indices come from a wave-local range [wpos, wend) that is topped up RT_GRAB rays at a time: one
+             * atomic on the single global counter per RT_GRAB rays instead of one per refill (same-address
+             * device-scope atomics serialise) */
+            const uint32_t n = __popcll(idle);
+            const uint32_t rank = __popcll(idle & lt);
+            const unsigned long long avail = wend - wpos;      /* wave-uniform */
+            unsigned long long idx = wpos + rank;
+            if (avail >= n) wpos += n;
+            else if (exhausted) { if (rank >= avail) idx = total; wpos = wend; }
+            else {
+                unsigned long long nb = 0;
+                if (lane == 0) nb = atomicAdd(next, (unsigned long long)RT_GRAB);
+                nb = __shfl(nb, 0);
+                if (rank >= avail) idx = nb + (rank - avail);
+                wpos = nb + (n - avail);
+                wend = nb + RT_GRAB;
+                if (wend >= total) {
+                    exhausted = true;
+                    wend = nb < total ? total : nb;
+                    if (wpos > wend) wpos = wend;
+                }
+            }
+            const unsigned long long got = __builtin_amdgcn_ballot_w64(s.st == ST_IDLE && idx < total);
+            if (lane == 0) traced += __popcll(got);
             if (s.st == ST_IDLE && idx < total) {
                 s.key = (uint32_t)(idx / (unsigned)S);
                 float4 ro = rays[2 * idx], rd = rays[2 * idx + 1];
@@ -768,10 +904,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __
             }
         }
         if (__builtin_amdgcn_ballot_w64(s.st != ST_IDLE) == 0ull) {
-            if (exhausted) break;
+            if (exhausted && wpos >= wend) break;
             continue;
         }
-        if (s.st == ST_TOP) shadow_advance_top(sc, s, stk, stride, cnt);
+        if (count_steps) { if (s.st == ST_TOP) c_ltop++; k_t1 = __builtin_readcyclecounter(); k_refill += k_t1 - k_t0; k_t0 = k_t1; }
+        if (s.st == ST_TOP) shadow_advance_top<QUANT>(sc, s, stk, stride, cnt);
+        if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_top += k_t1 - k_t0; k_t0 = k_t1; }
         /* node phase */
 #pragma unroll 1
         for (int k = 0; k < RT_NODE_STEPS; k++) {
@@ -779,22 +917,27 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene sc, const float4* __
             bool waiting = s.st == ST_MESH && s.tri_pos != TRI_NONE;
             unsigned long long mw = __builtin_amdgcn_ballot_w64(walking), mt = __builtin_amdgcn_ballot_w64(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
-            if (count_steps) { c_iter++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
-            if (walking) shadow_node_step(sc, s, stk, stride);
+            if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wn++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
+            if (walking) { if (QUANT) shadow_quant_step(sc, s, stk, stride); else shadow_node_step(sc, s, stk, stride); }
         }
+        if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_nodeph += k_t1 - k_t0; k_t0 = k_t1; }
         /* triangle phase */
 #pragma unroll 1
         for (int k = 0; k < RT_TRI_STEPS; k++) {
             bool pending = s.st == ST_MESH && s.tri_pos != TRI_NONE;
             if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
-            if (count_steps) { c_iter++; if (pending) c_tri++; }
-            if (pending) shadow_tri_step(sc, s, cnt);
+            if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wt++; if (pending) c_tri++; }
+            if (pending) { if (QUANT) shadow_quant_tri_step(sc, s, cnt); else shadow_tri_step(sc, s, cnt); }
         }
+        if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_triph += k_t1 - k_t0; }
     }
     if (lane == 0 && traced) atomicAdd(&ctr->rays_shadow, traced);
     if (count_steps) {
         atomicAdd(&ctr->sh_node_steps, c_node); atomicAdd(&ctr->sh_tri_steps, c_tri);
         atomicAdd(&ctr->sh_other_steps, c_other); atomicAdd(&ctr->sh_loop_iters, c_iter);
+        atomicAdd(&ctr->sh_top_lanes, c_ltop);
+        if (threadIdx.x == 0) { atomicAdd(&ctr->sh_clk_refill, k_refill); atomicAdd(&ctr->sh_clk_top, k_top); atomicAdd(&ctr->sh_clk_node, k_nodeph); atomicAdd(&ctr->sh_clk_tri, k_triph); }
+        if (threadIdx.x == 0) { atomicAdd(&ctr->sh_node_iters, c_wn); atomicAdd(&ctr->sh_tri_iters, c_wt); atomicAdd(&ctr->sh_top_iters, c_wtop); }
     }
 }
 

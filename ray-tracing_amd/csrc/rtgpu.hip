@@ -259,8 +259,13 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 EventPair* e2 = next_event(c, 1);
                 if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
                 HIP_TRY(c, hipEventRecord(e2->a, c->stream));
-                hipLaunchKernelGGL(k_shadow, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds, c->stream, c->sc, static_cast<const float4*>(c->srays.p),
-                                   threads, S, static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L, d_ctr, &d_ctr->work, c->count_steps ? 1 : 0);
+                uint32_t* cnt0 = static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L;
+                auto launch = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds, c->stream, c->sc, static_cast<const float4*>(c->srays.p),
+                                       threads, S, cnt0, d_ctr, &d_ctr->work);
+                };
+                if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<true, true>); else launch(k_shadow<true, false>); }
+                else { if (c->count_steps) launch(k_shadow<false, true>); else launch(k_shadow<false, false>); }
                 HIP_TRY(c, hipEventRecord(e2->b, c->stream));
             }
         }
@@ -286,8 +291,12 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
     c->stats.rays_shadow += c->h_ctr->rays_shadow;
     c->stats.nonfinite += c->h_ctr->nonfinite;
     if (c->count_steps)
-        fprintf(stderr, "[rtgpu] shadow steps: node %llu tri %llu other %llu lane-iterations %llu rays %llu\n", c->h_ctr->sh_node_steps,
-                c->h_ctr->sh_tri_steps, c->h_ctr->sh_other_steps, c->h_ctr->sh_loop_iters, c->h_ctr->rays_shadow);
+        fprintf(stderr, "[rtgpu] shadow steps: node %llu tri %llu other %llu lane-iterations %llu rays %llu; wave iterations: node %llu tri %llu top %llu (top lanes %llu)\n",
+                c->h_ctr->sh_node_steps, c->h_ctr->sh_tri_steps, c->h_ctr->sh_other_steps, c->h_ctr->sh_loop_iters, c->h_ctr->rays_shadow,
+                c->h_ctr->sh_node_iters, c->h_ctr->sh_tri_iters, c->h_ctr->sh_top_iters, c->h_ctr->sh_top_lanes);
+    if (c->count_steps)
+        fprintf(stderr, "[rtgpu] shadow wave clocks: refill %llu top %llu node phase %llu triangle phase %llu\n", c->h_ctr->sh_clk_refill,
+                c->h_ctr->sh_clk_top, c->h_ctr->sh_clk_node, c->h_ctr->sh_clk_tri);
     for (size_t i = 0; i < c->ev_used; i++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) {
@@ -296,6 +305,89 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         }
     }
     return RT_OK;
+}
+
+
+/* ---- quantised shadow nodes (see rt_kernels.h). Every child box of a mesh tree is rounded OUTWARD to
+ * 16-bit planes in the frame (qmin, qstep) of the mesh, one extra quantum of padding on each side, and
+ * stored with the two links in 32 bytes: x,y,z of the left box as lo | hi << 16, then the right box,
+ * then the links. A child without triangles gets lo = 65535, hi = 0 (never entered). lbox receives
+ * the exact box of every leaf. Returns false if the boxes cannot be used this way: a non-finite or
+ * inverted box, or a child box that is not inside its parent's box (then "leaf box hit => every box
+ * above it hit" does not hold and the exact walk is used instead). */
+bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<rt_bvh_node>& nodes, int32_t empty_link, DMesh& dm,
+                   std::vector<uint4>& qnodes, std::vector<float4>& lbox) {
+    double gmin[3] = {INFINITY, INFINITY, INFINITY}, gmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t v = 0; v < m.vert_count; v++)
+        for (int k = 0; k < 3; k++) {
+            double x = d->positions[3 * (m.vert_first + v) + k];
+            if (!(std::fabs(x) < 1e30)) return false;
+            gmin[k] = std::min(gmin[k], x); gmax[k] = std::max(gmax[k], x);
+        }
+    float qmin[3], qstep[3];
+    for (int k = 0; k < 3; k++) {
+        double step = std::max((gmax[k] - gmin[k]) / 65000.0, 1e-30);
+        qstep[k] = (float)step;
+        if (!(qstep[k] > 0.f)) qstep[k] = 1e-30f;
+        qmin[k] = (float)(gmin[k] - 8.0 * (double)qstep[k]);
+        dm.qmin[k] = qmin[k]; dm.qstep[k] = qstep[k];
+    }
+    bool ok = true;
+    /* planes as the kernel decodes them: qmin + q*qstep with these very floats (its rounding is covered by the slack there) */
+    auto lo_q = [&](float v, int k) -> uint32_t {
+        double q = std::floor(((double)v - (double)qmin[k]) / (double)qstep[k]) - 1.0;
+        if (!(q >= 0.0)) { if (!(q > -4.0)) ok = false; q = 0.0; }
+        if (q > 65535.0) { ok = false; q = 65535.0; }
+        return (uint32_t)q;
+    };
+    auto hi_q = [&](float v, int k) -> uint32_t {
+        double q = std::ceil(((double)v - (double)qmin[k]) / (double)qstep[k]) + 1.0;
+        if (!(q <= 65535.0)) { ok = false; q = 65535.0; }
+        if (q < 0.0) { ok = false; q = 0.0; }
+        return (uint32_t)q;
+    };
+    auto leaf_box = [&](int32_t link, const float* mn, const float* mx) {
+        size_t first = (size_t)(-2 - (int64_t)link);
+        lbox[2 * first] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+        lbox[2 * first + 1] = make_float4(mx[1], mx[2], 0.f, 0.f);
+    };
+    const float ninf[3] = {-INFINITY, -INFINITY, -INFINITY}, pinf[3] = {INFINITY, INFINITY, INFINITY};
+    const int32_t groot = nodes.empty() || m.root < 0 ? -1 : (int32_t)(m.root + m.node_first);
+    if (m.root < 0) {      /* the whole mesh is one leaf: its triangles are always reached (the root has no box) */
+        const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + (-1 - m.root)];
+        if (lf.count) leaf_box((int32_t)(-2 - (int64_t)(lf.first + m.tri_first)), ninf, pinf);
+        return true;
+    }
+    (void)groot;
+    for (int64_t i = 0; i < m.node_count; i++) {
+        const rt_bvh_node& n = nodes[(size_t)(m.node_first + i)];
+        const float* mn[2] = {n.lmin, n.rmin};
+        const float* mx[2] = {n.lmax, n.rmax};
+        const int32_t link[2] = {n.left, n.right};
+        uint32_t w[6];
+        for (int s = 0; s < 2; s++) {
+            const bool empty = link[s] == empty_link;
+            for (int k = 0; k < 3; k++) {
+                if (empty) { w[3 * s + k] = 65535u; continue; }            /* lo = 65535, hi = 0 */
+                if (!(mn[s][k] <= mx[s][k]) || !(std::fabs(mn[s][k]) < 1e30f) || !(std::fabs(mx[s][k]) < 1e30f)) { ok = false; w[3 * s + k] = 0xFFFF0000u; continue; }
+                w[3 * s + k] = lo_q(mn[s][k], k) | (hi_q(mx[s][k], k) << 16);
+            }
+            if (empty) continue;
+            if (link[s] >= 0) {                                             /* nesting: the child's two boxes lie inside this one */
+                const rt_bvh_node& ch = nodes[(size_t)link[s]];
+                const float* cmn[2] = {ch.lmin, ch.rmin};
+                const float* cmx[2] = {ch.lmax, ch.rmax};
+                for (int t = 0; t < 2; t++)
+                    for (int k = 0; k < 3; k++)
+                        if (!(cmn[t][k] >= mn[s][k]) || !(cmx[t][k] <= mx[s][k])) ok = false;
+            } else leaf_box(link[s], mn[s], mx[s]);
+        }
+        uint4 a = make_uint4(w[0], w[1], w[2], w[3]);
+        uint4 b = make_uint4(w[4], w[5], (uint32_t)n.left, (uint32_t)n.right);
+        qnodes[2 * (size_t)(m.node_first + i)] = a;
+        qnodes[2 * (size_t)(m.node_first + i) + 1] = b;
+    }
+    return ok;
 }
 
 /* The links must form a tree no deeper than declared: the device stacks are sized by the declared depth
@@ -384,6 +476,12 @@ uint32_t rt_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code, u
 
 const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+int rt_uses_quantised_shadow_nodes(const rt_ctx* c) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_scene) return RT_ERR_STATE;
+    return c->sc.quant_ok ? 1 : 0;
+}
+
 int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
     if (!out) return RT_ERR_ARG;
     *out = nullptr;
@@ -445,6 +543,10 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     std::vector<uint4> ids((size_t)d->n_tris);
     std::vector<rt_bvh_node> nodes(d->mesh_nodes, d->mesh_nodes + d->n_mesh_nodes);
     std::vector<DMesh> meshes((size_t)d->n_meshes);
+    /* shadow walk (rt_kernels.h, "quantised shadow nodes"): 32-byte copies of the nodes + the exact box of every leaf */
+    std::vector<uint4> qnodes((size_t)d->n_mesh_nodes * 2, make_uint4(0u, 0u, 0u, 0u));
+    std::vector<float4> lbox(((size_t)d->n_tris + 1) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    bool quant_ok = true;
     int max_mesh_depth = 0;
     for (int mi = 0; mi < d->n_meshes; mi++) {
         const rt_mesh& m = d->meshes[mi];
@@ -496,7 +598,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         float amax = 0.f;
         for (int64_t v = 0; v < 3 * m.vert_count; v++) amax = std::max(amax, std::fabs(d->positions[3 * m.vert_first + v]));
         meshes[mi].delta = 8e-4f * amax + 1e-5f;
-        meshes[mi].pad = 0;
+        meshes[mi].amax = amax;
+        meshes[mi].pad[0] = meshes[mi].pad[1] = 0;
+        quant_ok = quantise_mesh(d, m, nodes, (int32_t)(-2 - d->n_tris), meshes[mi], qnodes, lbox) && quant_ok;
     }
     if (d->n_verts > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "too many vertices");
     std::vector<float> normals(d->normals, d->normals + 3 * d->n_verts);
@@ -561,6 +665,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     const rt_bvh_node* dtn = nullptr;
     if ((rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
         (rc = upload(c, nodes, &dn)) || (rc = upload(c, meshes, &sc.meshes)) ||
+        (rc = upload(c, qnodes, &sc.qnodes)) || (rc = upload(c, lbox, &sc.lbox)) ||
         (rc = upload(c, tnodes, &dtn)) || (rc = upload(c, tleaves, &sc.tleaves)) || (rc = upload(c, titems, &sc.titems)) ||
         (rc = upload(c, squares, &sc.squares)) || (rc = upload(c, spheres, &sc.spheres)) || (rc = upload(c, mats, &sc.mats)) ||
         (rc = upload(c, lights, &sc.lights)) || (rc = upload(c, sincos, &sc.sincos))) {
@@ -578,6 +683,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     }
     sc.top_cap = d->top_depth + 2;
     sc.stack_cap = sc.top_cap + max_mesh_depth + 2;
+    sc.quant_ok = (quant_ok && !getenv("RT_SHADOW_EXACT_NODES")) ? 1 : 0;
+    if (c->debug) fprintf(stderr, "[rtgpu] scene: %lld mesh nodes, depth %d, quantised shadow nodes %s\n", (long long)d->n_mesh_nodes, max_mesh_depth,
+                          sc.quant_ok ? "on" : "off");
     c->sc = sc;
     c->n_lights = d->n_lights;
     c->has_scene = true;

@@ -196,6 +196,49 @@ def test_small_batches_same_frame(rt, ctx, monkeypatch):
     assert st2.rays == st.rays
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["final", "mesh_gorilla"])
+def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
+    """The quantised 32-byte shadow nodes (default) and the exact 64-byte nodes give identical frames;
+    a tree whose boxes are not nested switches the quantised nodes off by itself."""
+    hs, os_ = scene_pair(rt, ctx, name)
+    cam = rt.default_camera(1.0, zoom=25.0) if name == "final" else rt.default_camera(1.0)
+    p = rt.make_params(64, 64, spp=2, max_depth=6, seed=3)
+    quant, qprim, qst = ctx.render(cam, p)
+    monkeypatch.setenv("RT_SHADOW_EXACT_NODES", "1")
+    c2 = rt.Context(0)
+    try:
+        c2.upload_scene(hs)
+        exact, eprim, est = c2.render(cam, p)
+    finally:
+        c2.close()
+    monkeypatch.delenv("RT_SHADOW_EXACT_NODES")
+    assert np.array_equal(bits(quant), bits(exact)) and np.array_equal(qprim, eprim)
+    assert qst.rays_shadow == est.rays_shadow
+    # shrink one child box of a mesh root below its own children's boxes: not nested any more
+    dp = hs.desc
+    d = dp.contents
+    m = d.meshes[0]
+    root = d.mesh_nodes[m.node_first + m.root]
+    assert root.left >= 0
+    keep = [root.lmax[k] for k in range(3)]
+    for k in range(3):
+        root.lmax[k] = root.lmin[k] + 0.25 * (keep[k] - root.lmin[k])
+    monkeypatch.setenv("RT_DEBUG", "1")
+    c3 = rt.Context(0)
+    try:
+        c3._check(c3.L.rt_upload_scene(c3.h, dp), "rt_upload_scene")
+        assert c3.L.rt_uses_quantised_shadow_nodes(c3.h) == 0
+        c3.set_camera(cam)
+        rgb3, _, st3 = c3.render(cam, p)
+        assert np.isfinite(rgb3).all() and st3.rays_shadow > 0
+    finally:
+        c3.close()
+        for k in range(3):
+            root.lmax[k] = keep[k]
+    assert ctx.L.rt_uses_quantised_shadow_nodes(ctx.h) == 1
+
+
 def test_drop_in_entry_point_writes_ppm(rt, ctx, tmp_path):
     hs, os_ = scene_pair(rt, ctx, "reflexion")
     gc, oc = rt.default_camera(1.0), O.default_camera(1.0)
