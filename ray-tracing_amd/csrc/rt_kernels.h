@@ -578,6 +578,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
 #ifndef RT_GRAB
 #define RT_GRAB 512u           /* rays a wave takes from the global counter at a time */
 #endif
+#ifndef RT_DEFER
+#define RT_DEFER 1            /* keep walking with one leaf pending (fuller triangle rounds) */
+#endif
+#ifndef RT_TRI_MIN
+#define RT_TRI_MIN 24         /* pending leaves that make a triangle round worthwhile */
+#endif
+#ifndef RT_TRI_MORE
+#define RT_TRI_MORE 16        /* pending leaves that justify another triangle step in the same round */
+#endif
 #ifndef RT_NODE_STEPS
 #define RT_NODE_STEPS 16      /* node-phase steps between two refill checks */
 #endif
@@ -697,7 +706,8 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
         else if (s.msp > sc.top_cap) link = stk[lds_index(--s.msp, stride)];
         else link = LINK_NONE;
     }
-    if (link < 0 && link != LINK_NONE) {
+    /* a leaf: its triangles become pending; with one leaf pending already the lane keeps the link and is blocked */
+    if (link < 0 && link != LINK_NONE && (!RT_DEFER || s.tri_pos == TRI_NONE)) {
         s.tri_pos = leaf_first(link);
         link = LINK_NONE;
     }
@@ -707,6 +717,7 @@ RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     const float4* q = sc.tri + 4 * (size_t)s.tri_pos;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     s.tri_pos = __float_as_uint(q2.w) != 0u ? TRI_NONE : s.tri_pos + 1;
+    if (RT_DEFER && s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link); s.link = LINK_NONE; }   /* the blocked leaf is next */
     float t, w0, w1, w2;
     if (tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
@@ -784,7 +795,7 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, int* stk, int str
         else if (s.msp > sc.top_cap) link = stk[lds_index(--s.msp, stride)];
         else link = LINK_NONE;
     }
-    if (link < 0 && link != LINK_NONE) {
+    if (link < 0 && link != LINK_NONE && (!RT_DEFER || s.tri_pos == TRI_NONE)) {
         s.tri_pos = leaf_first(link) | TRI_NEW;
         link = LINK_NONE;
     }
@@ -803,6 +814,7 @@ RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt
         reached = slab(s.r, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tEnter) && !(tEnter > s.prune_t);
     }
     s.tri_pos = (!reached || __float_as_uint(q2.w) != 0u) ? TRI_NONE : pos + 1;
+    if (RT_DEFER && s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link) | TRI_NEW; s.link = LINK_NONE; }
     float t, w0, w1, w2;
     if (reached && tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
@@ -913,19 +925,34 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         /* node phase */
 #pragma unroll 1
         for (int k = 0; k < RT_NODE_STEPS; k++) {
-            bool walking = s.st == ST_MESH && s.tri_pos == TRI_NONE;
-            bool waiting = s.st == ST_MESH && s.tri_pos != TRI_NONE;
+            /* a lane walks while it has a node to visit or something to pop; with RT_DEFER it may do so with one leaf
+             * pending, and is blocked (waiting) only by a second leaf or when nothing is left but the pending leaf */
+            const bool pend = s.tri_pos != TRI_NONE;
+            bool walking = s.st == ST_MESH && (RT_DEFER ? (s.link >= 0 || (s.link == LINK_NONE && (s.msp > sc.top_cap || !pend))) : !pend);
+            bool waiting = s.st == ST_MESH && !walking;
             unsigned long long mw = __builtin_amdgcn_ballot_w64(walking), mt = __builtin_amdgcn_ballot_w64(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wn++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
             if (walking) { if (QUANT) shadow_quant_step(sc, s, stk, stride); else shadow_node_step(sc, s, stk, stride); }
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_nodeph += k_t1 - k_t0; k_t0 = k_t1; }
-        /* triangle phase */
+        /* triangle phase: worth a round once enough lanes have a leaf pending, or when the walkers are the minority */
+        if (RT_DEFER) {
+            const bool pend = s.st == ST_MESH && s.tri_pos != TRI_NONE;
+            const bool canwalk = s.st == ST_MESH && (s.link >= 0 || (s.link == LINK_NONE && (s.msp > sc.top_cap || !pend)));
+            const int np = __popcll(__builtin_amdgcn_ballot_w64(pend)), nw = __popcll(__builtin_amdgcn_ballot_w64(canwalk));
+            const int nb = __popcll(__builtin_amdgcn_ballot_w64(pend && !canwalk));
+            if (np < RT_TRI_MIN && nw > nb && nw > 0) continue;
+        }
 #pragma unroll 1
         for (int k = 0; k < RT_TRI_STEPS; k++) {
             bool pending = s.st == ST_MESH && s.tri_pos != TRI_NONE;
-            if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
+            const int np = __popcll(__builtin_amdgcn_ballot_w64(pending));
+            if (np == 0) break;
+            if (RT_DEFER && k > 0 && np < RT_TRI_MORE) {      /* a thin follow-up round only if nobody could walk instead */
+                const bool canwalk = s.st == ST_MESH && (s.link >= 0 || (s.link == LINK_NONE && (s.msp > sc.top_cap || !pending)));
+                if (__builtin_amdgcn_ballot_w64(canwalk) != 0ull) break;
+            }
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wt++; if (pending) c_tri++; }
             if (pending) { if (QUANT) shadow_quant_tri_step(sc, s, cnt); else shadow_tri_step(sc, s, cnt); }
         }
