@@ -857,6 +857,14 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
     rays[2 * idx + 1] = make_float4(d.x, d.y, d.z, 0.f);
 }
 
+/* A lane inside a mesh can take a node step unless a pending leaf blocks it: with a leaf pending it may still
+ * visit nodes and pop, but not take on a second leaf (the cursor then keeps that leaf's link) and not leave the
+ * mesh. Without a pending leaf every cursor value has a step to take (a leaf link -- e.g. a mesh that is one
+ * leaf -- becomes pending, an exhausted walk returns to the top level). */
+RT_DEV bool can_walk(const ShadowLane& s, int top_cap) {
+    if (s.tri_pos == TRI_NONE) return true;
+    return s.link >= 0 || (s.link == LINK_NONE && s.msp > top_cap);
+}
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
 template <bool QUANT, bool COUNT>      /* COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
@@ -928,7 +936,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             /* a lane walks while it has a node to visit or something to pop; with RT_DEFER it may do so with one leaf
              * pending, and is blocked (waiting) only by a second leaf or when nothing is left but the pending leaf */
             const bool pend = s.tri_pos != TRI_NONE;
-            bool walking = s.st == ST_MESH && (RT_DEFER ? (s.link >= 0 || (s.link == LINK_NONE && (s.msp > sc.top_cap || !pend))) : !pend);
+            bool walking = s.st == ST_MESH && (RT_DEFER ? can_walk(s, sc.top_cap) : !pend);
             bool waiting = s.st == ST_MESH && !walking;
             unsigned long long mw = __builtin_amdgcn_ballot_w64(walking), mt = __builtin_amdgcn_ballot_w64(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
@@ -939,7 +947,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         /* triangle phase: worth a round once enough lanes have a leaf pending, or when the walkers are the minority */
         if (RT_DEFER) {
             const bool pend = s.st == ST_MESH && s.tri_pos != TRI_NONE;
-            const bool canwalk = s.st == ST_MESH && (s.link >= 0 || (s.link == LINK_NONE && (s.msp > sc.top_cap || !pend)));
+            const bool canwalk = s.st == ST_MESH && can_walk(s, sc.top_cap);
             const int np = __popcll(__builtin_amdgcn_ballot_w64(pend)), nw = __popcll(__builtin_amdgcn_ballot_w64(canwalk));
             const int nb = __popcll(__builtin_amdgcn_ballot_w64(pend && !canwalk));
             if (np < RT_TRI_MIN && nw > nb && nw > 0) continue;
@@ -950,7 +958,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             const int np = __popcll(__builtin_amdgcn_ballot_w64(pending));
             if (np == 0) break;
             if (RT_DEFER && k > 0 && np < RT_TRI_MORE) {      /* a thin follow-up round only if nobody could walk instead */
-                const bool canwalk = s.st == ST_MESH && (s.link >= 0 || (s.link == LINK_NONE && (s.msp > sc.top_cap || !pending)));
+                const bool canwalk = s.st == ST_MESH && can_walk(s, sc.top_cap);
                 if (__builtin_amdgcn_ballot_w64(canwalk) != 0ull) break;
             }
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wt++; if (pending) c_tri++; }
