@@ -41,7 +41,17 @@ typedef struct {
     float ior;              /* index_medium */
     float transparency;
     float reflectivity;
+    /* Image texture and normal map (Material.h:24-31,86-138; applied at Scene.h:187-202). 0 = none (hasTexture /
+     * hasNormalMap false), otherwise 1 + index into rt_scene_desc::textures, so a zeroed struct means "no images". */
+    int32_t texture;
+    int32_t normal_map;
+    double material_scale;  /* materialScale (Material.h:31); 0.0 is read as the reference's default 1.0 */
 } rt_material;
+
+/* An image as stbi_load returns it (Material.h:128-138): rows top to bottom, `channels` (>= 3) bytes per texel,
+ * the first three are read as r, g, b (Material.h:92-93,102-103). Decoding files is the caller's business
+ * (the reference uses stb_image; include/rthost.h reads the binary PPMs the reference's scenes use). */
+typedef struct { int32_t width, height, channels; int32_t pad0; const uint8_t* texels; } rt_texture;
 
 /* Scene.h:20-34 (Light): spherical area light. */
 typedef struct { float pos[3]; float radius; float color[3]; float pad0; } rt_light;
@@ -97,6 +107,7 @@ typedef struct {
     int32_t n_top_leaves; const rt_bvh_leaf* top_leaves;
     int32_t n_top_items;  const uint32_t* top_items;                         /* object ordinals in leaf order */
     int32_t top_root;     int32_t top_depth;
+    int32_t n_textures;   const rt_texture* textures;                        /* may be 0 / NULL */
 } rt_scene_desc;
 
 /* Camera fields (Camera.h, Camera.cpp:24-38). rt_set_camera derives what Camera::apply

@@ -49,7 +49,13 @@ struct Material {
     double shininess = 0.0;   /* unset in the reference's ctor; defined 0.0 here */
     int type = RT_MAT_DIFFUSE;
     float index_medium = 1.0f, transparency = 0.0f, reflectivity = 0.0f;
+    /* Material.h:24-31: the images live in Scene::textures here (the reference keeps raw stbi pointers per material) */
+    int texture = -1, normalMap = -1;                  /* hasTexture / hasNormalMap = index >= 0 */
+    double materialScale = 1.;
 };
+struct Image { int width = 0, height = 0, channels = 0; std::vector<uint8_t> data; };   /* stbi_load result */
+/* Binary PPM (P6, maxval 255), the format of the reference's .ppm textures and normal maps. */
+bool load_ppm(const std::string& filename, Image& out);
 
 struct AABB {                 /* AccelerationStruct.h:11-70 */
     Vec3 min, max;
@@ -98,6 +104,7 @@ struct Square {               /* Square.h:18-125: the four transformed vertices 
     void translate(const Vec3& t);
     void scale(const Vec3& s);
     void rotate_x(float angle);
+    void rotate_y(float angle);
     AABB getBoundingBox() const;                        /* Square.h:113-123 */
 };
 struct Sphere {               /* Sphere.h:37-43 */
@@ -131,6 +138,7 @@ public:
     std::vector<Sphere> spheres;
     std::vector<Square> squares;
     std::vector<Light> lights;
+    std::vector<Image> textures;                        /* Material::texture / normalMap index into this */
     FlatTree sceneBvh;
     int topDepthLimit = 3;                              /* AccelerationStruct.h:121 */
 
@@ -139,7 +147,11 @@ public:
     void buildSceneBvh();                               /* sceneBvh = BVH_Node::buildBVH(squares, spheres, meshes) */
     bool setup_refraction_scene();                      /* Scene.h:468-552 */
     bool setup_reflexion_scene();                       /* Scene.h:554-599 */
+    bool setup_reflexion_chamber();                     /* Scene.h:601-714 */
     bool setup_final_scene();                           /* Scene.h:800-970 */
+    /* Material::loadTexture / loadNormalMap (Material.h:128-138) for files under the image directory; -1 on failure */
+    int loadImage(const std::string& relative_path);
+    int addImage(int width, int height, int channels, const uint8_t* texels);
     bool setup_mesh_scene(const std::string& off, bool unit);   /* Scene.h:716-781 (gorilla block) */
     bool setup_soup_scene(int64_t ntris);               /* BASELINE config 5 */
     bool setup(const std::string& name);
@@ -157,10 +169,12 @@ private:
     std::vector<uint32_t> f_tris, f_items;
     std::vector<rt_bvh_node> f_nodes;
     std::vector<rt_bvh_leaf> f_leaves;
+    std::vector<rt_texture> f_textures;
     rt_scene_desc f_desc;
 };
 
 void set_asset_dir(const std::string& dir);
+void set_image_dir(const std::string& dir);            /* stands for the reference's "assets/img/" */
 
 /* BVH_Node::buildBVH for triangles (AccelerationStruct.cpp:91-113,151-195). */
 void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out);
@@ -182,6 +196,9 @@ typedef struct rth_scene rth_scene;
 rth_scene* rth_scene_new(void);
 void rth_scene_free(rth_scene*);
 void rth_set_asset_dir(const char* dir);
+void rth_set_image_dir(const char* dir);
+/* Returns the value for rt_material::texture / normal_map (1 + index), or a negative rt_status. The data is copied. */
+int rth_add_texture(rth_scene*, int width, int height, int channels, const uint8_t* texels);
 /* "final", "refraction", "reflexion", "mesh_gorilla", "mesh_cow", "soup:<ntris>" */
 int rth_scene_setup(rth_scene*, const char* name);
 int rth_add_light(rth_scene*, const float pos[3], float radius, const float color[3]);

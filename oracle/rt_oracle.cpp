@@ -79,7 +79,10 @@ struct Mat {                                                                    
     double shininess = 0.0;     /* uninitialised in the reference; defined as 0.0 (hard parts) */
     int type = MAT_DIFFUSE;
     float ior = 1.0f, transparency = 0.0f, reflectivity = 0.0f;
+    int tex = -1, nmap = -1;    /* indices into orc_scene::textures (hasTexture / hasNormalMap) */
+    double scale = 1.;          /* materialScale, Material.h:31 */
 };
+struct Texture { int w = 0, h = 0, ch = 0; std::vector<uint8_t> data; };    /* stbi_load result, Material.h:24-27 */
 
 struct Node {
     bool leaf = true;
@@ -121,6 +124,7 @@ struct HitRec {                                                                 
 };
 
 std::string g_asset_dir = "assets/models";
+std::string g_image_dir = "assets/img";
 
 }  // namespace
 
@@ -129,6 +133,7 @@ struct orc_scene {
     std::vector<SphereObj> spheres;
     std::vector<SquareObj> squares;
     std::vector<Light> lights;
+    std::vector<Texture> textures;
     Tree top;
     int n_obj() const { return (int)(squares.size() + spheres.size() + meshes.size()); }
 };
@@ -278,7 +283,7 @@ HitRec mesh_intersect(const MeshObj& m, const Ray& ray, bool shadow) {
     return r;
 }
 
-/* Sphere::intersect, Sphere.h:86-146 (u,v omitted: only image textures read them). */
+/* Sphere::intersect, Sphere.h:86-146. */
 HitRec sphere_intersect(const SphereObj& s, const Ray& ray) {
     HitRec miss;
     V3 dir = ray.d;
@@ -309,6 +314,8 @@ HitRec sphere_intersect(const SphereObj& s, const Ray& ray) {
         r.t = t;
         r.nrm = n;
         r.pos = ray.o + ray.d * t;
+        r.u = 0.5 + (std::atan2((double)dir[2], (double)dir[0]) / (2. * M_PI));   /* Sphere.h:141-142, from the ray direction */
+        r.v = 0.5 + (std::asin((double)dir[1]) / M_PI);
     }
     r.mat = &s.mat;
     return r;
@@ -460,6 +467,18 @@ double schlick(double cosine, double ri) {
     return r0 + (1 - r0) * std::pow((1 - cosine), 5);
 }
 
+/* Material::getColorAt / getNormalAt, Material.h:86-104: nearest texel, % wrap, bytes / 255.0 narrowed to float.
+ * u, v are never negative on the reference's own primitives (a negative index would read out of bounds there);
+ * a negative remainder is wrapped into the image here. */
+V3 texel_at(const Texture& t, double u, double v, double scale) {
+    int pu = (int)(u * (double)t.w * scale) % t.w;
+    int pv = (int)(v * (double)t.h * scale) % t.h;
+    if (pu < 0) pu += t.w;
+    if (pv < 0) pv += t.h;
+    size_t i = ((size_t)pv * (size_t)t.w + (size_t)pu) * (size_t)t.ch;
+    return V3((float)(t.data[i] / 255.0), (float)(t.data[i + 1] / 255.0), (float)(t.data[i + 2] / 255.0));
+}
+
 /* Scene::rayTraceRecursive, Scene.h:174-280 */
 V3 trace(const TraceCtx& c, const Ray& ray, int remaining, uint64_t code, HitRec* firstHit) {
     if (code == 1) tl_stats.prim++; else tl_stats.sec++;
@@ -471,14 +490,27 @@ V3 trace(const TraceCtx& c, const Ray& ray, int remaining, uint64_t code, HitRec
         float omt = (float)(1.0 - (double)t);
         return omt * V3(1.0f) + t * V3(0.5f, 0.7f, 1.0f);
     }
-    const V3 P = h.pos, N = h.nrm;
+    const V3 P = h.pos;
+    V3 N = h.nrm;
     Mat m = *h.mat;
-    if (m.type == MAT_CHECKER) {                                              /* Material.h:153-161, Scene.h:51,192-197 */
+    const float uf = (float)h.u, vf = (float)h.v;                             /* Scene.h:184: intersectionUV is a Vec3 (floats) */
+    if (m.tex >= 0) {                                                         /* Scene.h:187-191 */
+        V3 col = texel_at(c.sc->textures[(size_t)m.tex], (double)uf, (double)vf, m.scale);
+        m.kd = col; m.ks = col;
+    } else if (m.type == MAT_CHECKER) {                                              /* Material.h:153-161, Scene.h:51,192-197 */
         float inv = (float)(1. / 3.f);
         int xi = (int)std::floor(inv * P[0]), yi = (int)std::floor(inv * P[1]), zi = (int)std::floor(inv * P[2]);
         bool even = (xi + yi + zi) % 2 == 0;
         V3 col = even ? V3(0.f) : V3(1.f);
         m.kd = col; m.ks = col;
+    }
+    if (m.nmap >= 0) {                                                        /* Scene.h:199-202, Material::applyTBN Material.h:118-126 */
+        V3 nm = texel_at(c.sc->textures[(size_t)m.nmap], (double)uf, (double)vf, m.scale);   /* not remapped to [-1,1] */
+        V3 tg(1.f, 0.f, 0.f);
+        V3 bt = cross(N, tg);
+        N = V3(tg[0] * nm[0] + bt[0] * nm[1] + N[0] * nm[2],                 /* Mat3(t,b,n columns) * nm, Vec3.h:156-163; not normalised */
+               tg[1] * nm[0] + bt[1] * nm[1] + N[1] * nm[2],
+               tg[2] * nm[0] + bt[2] * nm[1] + N[2] * nm[2]);
     }
     if (m.type == MAT_DIFFUSE || m.type == MAT_CHECKER || remaining <= 0) {  /* Scene.h:204-222 */
         color = V3(0.f);
@@ -715,6 +747,42 @@ struct QuadPts { SquareObj& q; V3& operator[](size_t i) { return q.vtx[i]; } };
 
 float frand01() { return (float)rand() / (float)RAND_MAX; }   /* (float) rand() / RAND_MAX */
 
+/* Binary PPM ("P6", comments, maxval 255): what stbi_load makes of the reference's .ppm assets (3 channels). */
+bool load_ppm(const std::string& path, int& w, int& h, std::vector<uint8_t>& px) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    auto token = [&](std::string& out) {
+        out.clear();
+        int ch = fgetc(f);
+        for (;;) {
+            while (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r') ch = fgetc(f);
+            if (ch == '#') { while (ch != '\n' && ch != EOF) ch = fgetc(f); continue; }
+            break;
+        }
+        while (ch != EOF && ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r') { out.push_back((char)ch); ch = fgetc(f); }
+        return !out.empty();      /* exactly one whitespace byte after the token has been consumed */
+    };
+    std::string t;
+    bool ok = token(t) && t == "P6";
+    int mx = 0;
+    ok = ok && token(t) && (w = atoi(t.c_str())) > 0;
+    ok = ok && token(t) && (h = atoi(t.c_str())) > 0;
+    ok = ok && token(t) && (mx = atoi(t.c_str())) == 255;
+    if (ok) {
+        px.resize((size_t)w * h * 3);
+        ok = fread(px.data(), 1, px.size(), f) == px.size();
+    }
+    fclose(f);
+    return ok;
+}
+int add_ppm(orc_scene& sc, const std::string& rel) {
+    Texture t;
+    if (!load_ppm(g_image_dir + "/" + rel, t.w, t.h, t.data)) return -1;
+    t.ch = 3;
+    sc.textures.push_back(std::move(t));
+    return (int)sc.textures.size() - 1;
+}
+
 Light make_light(const V3& p, float radius) { Light l; l.pos = p; l.radius = radius; l.color = V3(1.f, 1.f, 1.f); return l; }
 
 SquareObj big_floor(float sx, float sy) {
@@ -780,6 +848,39 @@ int setup_mesh_scene(orc_scene& sc, const char* file, bool unit) {
     translate(m.pos, m.pos.size(), V3(0.f, -1.05f, 0.f));
     recompute_normals(m);
     m.mat.kd = V3(1.f, 1.f, 1.f); m.mat.ks = V3(1.f, 1.f, 1.f); m.mat.shininess = 16;
+    return 0;
+}
+
+/* Scene::setup_reflexion_chamber, Scene.h:601-714: six walls (five mirrors, a checker floor with the normal map
+ * n3.ppm), two small lights, a flamingo. */
+int setup_reflexion_chamber(orc_scene& sc) {
+    sc.lights.push_back(make_light(V3(1.f, 1.5f, 1.f), .1f));
+    sc.lights.push_back(make_light(V3(-1.f, 1.5f, -1.f), .1f));
+    for (int i = 0; i < 6; i++) {
+        SquareObj w = make_quad(V3(-1.f, -1.f, 0.f), V3(1.f, 0.f, 0.f), V3(0.f, 1.f, 0.f), 2.f, 2.f);
+        QuadPts p{w};
+        apply_matrix(p, 4, scale_matrix(V3(2.f, 2.f, 1.f)));
+        translate(p, 4, V3(0.f, 0.f, -2.f));
+        w.mat.kd = V3(1.f); w.mat.ks = V3(1.f); w.mat.shininess = 16;
+        if (i == 0) { w.mat.scale = 4; w.mat.type = MAT_MIRROR; w.mat.reflectivity = 0.9f; }                        /* back wall */
+        if (i == 1) { apply_matrix(p, 4, rot_y(90.f)); w.mat.kd = V3(1.f, .75f, .75f); w.mat.ks = V3(1.f, .75f, .75f);
+                      w.mat.type = MAT_MIRROR; w.mat.reflectivity = 0.9f; }                                         /* left wall */
+        if (i == 2) { apply_matrix(p, 4, rot_y(-90.f)); w.mat.kd = V3(.75f, 1.f, .75f); w.mat.ks = V3(.75f, 1.f, .75f);
+                      w.mat.type = MAT_MIRROR; w.mat.reflectivity = 0.9f; }                                         /* right wall */
+        if (i == 3) { apply_matrix(p, 4, rot_x(-90.f)); w.mat.type = MAT_CHECKER;                                   /* floor */
+                      w.mat.nmap = add_ppm(sc, "normalMaps/n3.ppm"); if (w.mat.nmap < 0) return -2; }
+        if (i == 4) { apply_matrix(p, 4, rot_x(90.f)); w.mat.type = MAT_MIRROR; w.mat.reflectivity = 0.9f; }        /* ceiling */
+        if (i == 5) { apply_matrix(p, 4, rot_y(180.f)); w.mat.type = MAT_MIRROR; w.mat.reflectivity = 0.9f; }       /* front wall */
+        sc.squares.push_back(w);
+    }
+    sc.meshes.emplace_back();
+    MeshObj& m = sc.meshes.back();
+    if (!add_off_mesh(sc, "flamingo.off", m)) return -2;
+    apply_matrix(m.pos, m.pos.size(), scale_matrix(V3(0.0125f)));
+    translate(m.pos, m.pos.size(), V3(0.f, -1.55f, 0.f));
+    recompute_normals(m);
+    m.mat.kd = V3(1.f, 0.753f, 0.796f); m.mat.ks = V3(1.f, 0.753f, 0.796f); m.mat.shininess = 16;
+    m.mat.transparency = 1.0f; m.mat.ior = 1.2f;
     return 0;
 }
 
@@ -1005,12 +1106,14 @@ void fill_mat(const Mat& m, orc_material* o) {
     memset(o, 0, sizeof(*o));
     for (int k = 0; k < 3; k++) { o->ka[k] = m.ka[k]; o->kd[k] = m.kd[k]; o->ks[k] = m.ks[k]; }
     o->shininess = m.shininess; o->type = m.type; o->ior = m.ior; o->transparency = m.transparency; o->reflectivity = m.reflectivity;
+    o->texture = m.tex + 1; o->normal_map = m.nmap + 1; o->material_scale = m.scale;
 }
 Mat from_mat(const orc_material* o) {
     Mat m;
     if (!o) return m;
     m.ka = V3(o->ka[0], o->ka[1], o->ka[2]); m.kd = V3(o->kd[0], o->kd[1], o->kd[2]); m.ks = V3(o->ks[0], o->ks[1], o->ks[2]);
     m.shininess = o->shininess; m.type = o->type; m.ior = o->ior; m.transparency = o->transparency; m.reflectivity = o->reflectivity;
+    m.tex = o->texture - 1; m.nmap = o->normal_map - 1; m.scale = o->material_scale == 0.0 ? 1.0 : o->material_scale;
     return m;
 }
 
@@ -1029,6 +1132,39 @@ extern "C" {
 orc_scene* orc_scene_new(void) { return new orc_scene(); }
 void orc_scene_free(orc_scene* s) { delete s; }
 void orc_set_asset_dir(const char* dir) { g_asset_dir = dir; }
+void orc_set_image_dir(const char* dir) { g_image_dir = dir; }
+
+int orc_add_texture(orc_scene* sc, int width, int height, int channels, const uint8_t* texels) {
+    if (!sc || width <= 0 || height <= 0 || channels < 3 || !texels) return -1;
+    Texture t;
+    t.w = width; t.h = height; t.ch = channels;
+    t.data.assign(texels, texels + (size_t)width * height * channels);
+    sc->textures.push_back(std::move(t));
+    return (int)sc->textures.size() - 1;
+}
+
+int orc_get_texture(const orc_scene* sc, int i, int* width, int* height, int* channels, uint8_t* texels) {
+    if (!sc || i < 0 || i >= (int)sc->textures.size()) return -1;
+    const Texture& t = sc->textures[(size_t)i];
+    if (width) *width = t.w;
+    if (height) *height = t.h;
+    if (channels) *channels = t.ch;
+    if (texels) memcpy(texels, t.data.data(), t.data.size());
+    return 0;
+}
+
+int orc_load_ppm(const char* path, int* width, int* height, uint8_t* texels, int64_t max_bytes) {
+    std::vector<uint8_t> px;
+    int w = 0, h = 0;
+    if (!load_ppm(path, w, h, px)) return -1;
+    if (width) *width = w;
+    if (height) *height = h;
+    if (texels) {
+        if ((int64_t)px.size() > max_bytes) return -2;
+        memcpy(texels, px.data(), px.size());
+    }
+    return 0;
+}
 
 int orc_load_off(const char* path, float* verts, int max_v, uint32_t* tris, int max_t, int* nv, int* nt) {
     std::vector<V3> pos; std::vector<uint32_t> tri;
@@ -1048,6 +1184,7 @@ int orc_scene_setup(orc_scene* sc, const char* name) {
     if (n == "reflexion") return setup_reflexion(*sc);
     if (n == "mesh_gorilla") return setup_mesh_scene(*sc, "gorilla18_fixed.obj.off", false);
     if (n == "mesh_cow") return setup_mesh_scene(*sc, "cow.off", true);
+    if (n == "reflexion_chamber") return setup_reflexion_chamber(*sc);
     if (n.rfind("soup:", 0) == 0) return setup_soup(*sc, atoll(n.c_str() + 5));
     return -1;
 }
@@ -1057,7 +1194,11 @@ int orc_add_light(orc_scene* sc, const float pos[3], float radius, const float c
     sc->lights.push_back(l);
     return 0;
 }
+static bool mat_images_ok(const orc_scene* sc, const Mat& m) {
+    return m.tex < (int)sc->textures.size() && m.nmap < (int)sc->textures.size() && m.tex >= -1 && m.nmap >= -1;
+}
 int orc_add_square(orc_scene* sc, const float verts[12], const orc_material* m) {
+    if (!mat_images_ok(sc, from_mat(m))) return -1;
     SquareObj q;
     for (int j = 0; j < 4; j++) q.vtx[j] = V3(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]);
     q.mat = from_mat(m);
@@ -1065,11 +1206,13 @@ int orc_add_square(orc_scene* sc, const float verts[12], const orc_material* m) 
     return 0;
 }
 int orc_add_sphere(orc_scene* sc, const float c[3], float radius, const orc_material* m) {
+    if (!mat_images_ok(sc, from_mat(m))) return -1;
     SphereObj s; s.c = V3(c[0], c[1], c[2]); s.r = radius; s.mat = from_mat(m);
     sc->spheres.push_back(s);
     return 0;
 }
 int orc_add_mesh(orc_scene* sc, const float* verts, int nv, const uint32_t* tris, int nt, const orc_material* mt) {
+    if (!mat_images_ok(sc, from_mat(mt))) return -1;
     sc->meshes.emplace_back();
     MeshObj& m = sc->meshes.back();
     m.pos.resize(nv);

@@ -32,6 +32,9 @@ typedef struct {
     float ior;            /* index_medium */
     float transparency;
     float reflectivity;
+    int32_t texture;      /* 0 = none (hasTexture false), else 1 + index of an image added with orc_add_texture (Material::textureData) */
+    int32_t normal_map;   /* same for Material::normalMapData / hasNormalMap */
+    double material_scale;/* Material.h:31 materialScale; 0.0 is read as the reference's default 1.0 */
 } orc_material;
 
 /* Camera fields of Camera.h / Camera.cpp:24-38; the oracle turns them into the
@@ -67,7 +70,7 @@ typedef struct {
     float t;
     float pos[3];
     float nrm[3];
-    float u, v;       /* w0,w1 for meshes (Mesh.cpp:133-134), u,v for squares; 0 for spheres */
+    float u, v;       /* w0,w1 for meshes (Mesh.cpp:133-134), u,v for squares, Sphere.h:141-142 for spheres (narrowed to float as Scene.h:184 does) */
 } orc_hit;
 
 orc_scene* orc_scene_new(void);
@@ -78,7 +81,17 @@ void orc_set_asset_dir(const char* dir);
 /* Mesh::loadOFF (Mesh.cpp:5-23) on a file; returns 0 and counts, fills caller arrays if non-null. */
 int orc_load_off(const char* path, float* verts, int max_v, uint32_t* tris, int max_t, int* nv, int* nt);
 
-/* Named scenes: "final", "refraction", "reflexion", "mesh_gorilla", "mesh_cow", "soup:<ntris>". */
+/* Directory that stands for the reference's "assets/img/" (normalMaps/, sphereTextures/ below it). */
+void orc_set_image_dir(const char* dir);
+/* An image as stbi_load returns it (Material.h:128-138): rows top to bottom, `channels` (>= 3) bytes per texel.
+ * Returns its index for orc_material::texture / normal_map, or -1. The data is copied. */
+int orc_add_texture(orc_scene*, int width, int height, int channels, const uint8_t* texels);
+/* Size and (if texels is non-null) bytes of image i. */
+int orc_get_texture(const orc_scene*, int i, int* width, int* height, int* channels, uint8_t* texels);
+/* Binary PPM (P6, maxval 255) as the reference's assets are; returns 0 and the size, fills texels (3 bytes each) if non-null. */
+int orc_load_ppm(const char* path, int* width, int* height, uint8_t* texels, int64_t max_bytes);
+
+/* Named scenes: "final", "refraction", "reflexion", "reflexion_chamber", "mesh_gorilla", "mesh_cow", "soup:<ntris>". */
 int orc_scene_setup(orc_scene*, const char* name);
 
 /* Free-form scenes (already-transformed geometry). */

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("RT_LIB", os.path.join(_HERE, "librtgpu.so"))   # RT_LIB: developer A/B knob
 DEFAULT_ASSET_DIR = os.path.join(ROOT, "tests", "golden", "models")
+DEFAULT_IMAGE_DIR = os.path.join(ROOT, "tests", "golden", "img")
 
 RT_OK = 0
 
@@ -26,7 +27,13 @@ class RtError(RuntimeError):
 class Material(C.Structure):
     _fields_ = [("ka", C.c_float * 3), ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("pad0", C.c_float),
                 ("shininess", C.c_double), ("type", C.c_int32), ("ior", C.c_float),
-                ("transparency", C.c_float), ("reflectivity", C.c_float)]
+                ("transparency", C.c_float), ("reflectivity", C.c_float),
+                ("texture", C.c_int32), ("normal_map", C.c_int32), ("material_scale", C.c_double)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("pad0", C.c_int32),
+                ("texels", C.POINTER(C.c_uint8))]
 
 
 class Light(C.Structure):
@@ -70,7 +77,8 @@ class SceneDesc(C.Structure):
                 ("n_top_nodes", C.c_int32), ("top_nodes", C.POINTER(BvhNode)),
                 ("n_top_leaves", C.c_int32), ("top_leaves", C.POINTER(BvhLeaf)),
                 ("n_top_items", C.c_int32), ("top_items", C.POINTER(C.c_uint32)),
-                ("top_root", C.c_int32), ("top_depth", C.c_int32)]
+                ("top_root", C.c_int32), ("top_depth", C.c_int32),
+                ("n_textures", C.c_int32), ("textures", C.POINTER(Texture))]
 
 
 class Camera(C.Structure):
@@ -103,7 +111,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame",
            "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_get_stats",
            "rt_intersect", "rt_occluded", "rt_trace", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes",
-           "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_scene_setup", "rth_add_light",
+           "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
            "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_scene_desc",
            "rth_ray_trace_from_camera", "rth_write_ppm", "rth_load_off"]
 
@@ -149,6 +157,9 @@ def lib():
     L.rth_scene_free.restype = None
     L.rth_set_asset_dir.argtypes = [C.c_char_p]
     L.rth_set_asset_dir.restype = None
+    L.rth_set_image_dir.argtypes = [C.c_char_p]
+    L.rth_set_image_dir.restype = None
+    L.rth_add_texture.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     L.rth_scene_setup.argtypes = [vp, C.c_char_p]
     L.rth_add_light.argtypes = [vp, vp, C.c_float, vp]
     L.rth_add_square.argtypes = [vp, vp, C.POINTER(Material)]
@@ -162,6 +173,7 @@ def lib():
     L.rth_write_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     L.rth_load_off.argtypes = [C.c_char_p, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.rth_set_asset_dir(DEFAULT_ASSET_DIR.encode())
+    L.rth_set_image_dir(DEFAULT_IMAGE_DIR.encode())
     _lib = L
     return L
 
@@ -226,13 +238,26 @@ class HostScene:
         c = np.asarray(color, np.float32)
         self.L.rth_add_light(self.h, _ptr(p), radius, _ptr(c))
 
+    def add_texture(self, texels):
+        """texels: uint8 array (h, w, channels>=3), rows top to bottom (stbi_load layout).
+        Returns the value for Material.texture / normal_map."""
+        t = np.ascontiguousarray(texels, np.uint8)
+        rc = self.L.rth_add_texture(self.h, t.shape[1], t.shape[0], t.shape[2], _ptr(t))
+        if rc <= 0:
+            raise RtError(f"rth_add_texture failed ({rc})")
+        return rc
+
     def add_square(self, verts, mat):
         v = np.ascontiguousarray(verts, np.float32).reshape(12)
-        self.L.rth_add_square(self.h, _ptr(v), C.byref(mat))
+        rc = self.L.rth_add_square(self.h, _ptr(v), C.byref(mat))
+        if rc != RT_OK:
+            raise RtError(f"rth_add_square failed ({rc})")
 
     def add_sphere(self, center, radius, mat):
         c = np.asarray(center, np.float32)
-        self.L.rth_add_sphere(self.h, _ptr(c), radius, C.byref(mat))
+        rc = self.L.rth_add_sphere(self.h, _ptr(c), radius, C.byref(mat))
+        if rc != RT_OK:
+            raise RtError(f"rth_add_sphere failed ({rc})")
 
     def add_mesh(self, verts, tris, mat):
         v = np.ascontiguousarray(verts, np.float32)
@@ -280,6 +305,9 @@ class HostScene:
             "squares": [d.squares[i] for i in range(d.n_squares)],
             "lights": [d.lights[i] for i in range(d.n_lights)],
             "materials": [d.materials[i] for i in range(d.n_materials)],
+            "textures": [np.ctypeslib.as_array(d.textures[i].texels, shape=(d.textures[i].height, d.textures[i].width,
+                                                                             d.textures[i].channels)).copy()
+                         for i in range(d.n_textures)],
         }
         return out
 

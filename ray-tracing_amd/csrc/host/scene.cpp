@@ -21,6 +21,38 @@ namespace rth {
 
 static std::string g_asset_dir = "assets/models";
 void set_asset_dir(const std::string& dir) { g_asset_dir = dir; }
+static std::string g_image_dir = "assets/img";
+void set_image_dir(const std::string& dir) { g_image_dir = dir; }
+
+/* Binary PPM: "P6", whitespace / # comments, width, height, maxval 255, one whitespace byte, then rgb bytes.
+ * This is what stbi_load returns for the reference's .ppm assets (3 channels, rows top to bottom). */
+bool load_ppm(const std::string& filename, Image& out) {
+    FILE* f = std::fopen(filename.c_str(), "rb");
+    if (!f) return false;
+    int c = std::fgetc(f);
+    auto next = [&](std::string& tok) {
+        tok.clear();
+        for (;;) {
+            while (c == ' ' || c == '\t' || c == '\r' || c == '\n') c = std::fgetc(f);
+            if (c != '#') break;
+            while (c != '\n' && c != EOF) c = std::fgetc(f);
+        }
+        while (c != EOF && c != ' ' && c != '\t' && c != '\r' && c != '\n') { tok.push_back((char)c); c = std::fgetc(f); }
+        return !tok.empty();
+    };
+    std::string tok;
+    bool ok = next(tok) && tok == "P6";
+    ok = ok && next(tok) && (out.width = std::atoi(tok.c_str())) > 0;
+    ok = ok && next(tok) && (out.height = std::atoi(tok.c_str())) > 0;
+    ok = ok && next(tok) && std::atoi(tok.c_str()) == 255;     /* `c` is the single whitespace byte after maxval, already consumed */
+    if (ok) {
+        out.channels = 3;
+        out.data.resize((size_t)out.width * out.height * 3);
+        ok = std::fread(out.data.data(), 1, out.data.size(), f) == out.data.size();
+    }
+    std::fclose(f);
+    return ok;
+}
 
 /* ------------------------------------------------------------------ Vec3.h */
 float Vec3::squareLength() const { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }          /* Vec3.h:29 */
@@ -121,6 +153,7 @@ void Square::setQuad(const Vec3& bottomLeft, const Vec3& rightVector, const Vec3
 void Square::translate(const Vec3& t) { for (Vec3& p : vertices) p = p + t; }
 void Square::scale(const Vec3& s) { Mat3 m = scaleMatrix(s); for (Vec3& p : vertices) p = m * p; }
 void Square::rotate_x(float angle) { Mat3 m = rotX(angle); for (Vec3& p : vertices) p = m * p; }
+void Square::rotate_y(float angle) { Mat3 m = rotY(angle); for (Vec3& p : vertices) p = m * p; }
 AABB Square::getBoundingBox() const {
     Vec3 mn = vertices[0], mx = vertices[0];
     for (const Vec3& p : vertices)
@@ -272,7 +305,21 @@ void buildBVH(const std::vector<AABB>& objectBoxes, int deepLimit, FlatTree& out
 }
 
 /* ------------------------------------------------------------------ Scene */
-void Scene::clear() { meshes.clear(); spheres.clear(); squares.clear(); lights.clear(); sceneBvh = FlatTree(); }
+void Scene::clear() { meshes.clear(); spheres.clear(); squares.clear(); lights.clear(); textures.clear(); sceneBvh = FlatTree(); }
+int Scene::loadImage(const std::string& relative_path) {
+    Image img;
+    if (!load_ppm(g_image_dir + "/" + relative_path, img)) return -1;
+    textures.push_back(std::move(img));
+    return (int)textures.size() - 1;
+}
+int Scene::addImage(int width, int height, int channels, const uint8_t* texels) {
+    if (width <= 0 || height <= 0 || channels < 3 || !texels) return -1;
+    Image img;
+    img.width = width; img.height = height; img.channels = channels;
+    img.data.assign(texels, texels + (size_t)width * height * channels);
+    textures.push_back(std::move(img));
+    return (int)textures.size() - 1;
+}
 void Scene::applySettings(Settings set) { for (Mesh& m : meshes) m.buildTree(set.tree_subdivide); }
 void Scene::buildSceneBvh() {
     std::vector<AABB> boxes;                      /* squares, spheres, meshes: AccelerationStruct.cpp:123-134 */
@@ -349,6 +396,40 @@ bool Scene::setup_mesh_scene(const std::string& off, bool unit) {
     m.translate(Vec3(0.f, -1.05f, 0.f));
     m.build_arrays();
     setColour(m.material, 1.f, 1.f, 1.f, 16);
+    m.buildTree(3);
+    buildSceneBvh();
+    return true;
+}
+
+/* Scene::setup_reflexion_chamber, Scene.h:601-714 */
+bool Scene::setup_reflexion_chamber() {
+    clear();
+    lights.push_back(pointLight(1.f, 1.5f, 1.f, .1f));
+    lights.push_back(pointLight(-1.f, 1.5f, -1.f, .1f));
+    for (int i = 0; i < 6; i++) {                                   /* Scene.h:630-639 */
+        Square s;
+        s.setQuad(Vec3(-1.f, -1.f, 0.f), Vec3(1.f, 0.f, 0.f), Vec3(0.f, 1.f, 0.f), 2.f, 2.f);
+        s.scale(Vec3(2.f, 2.f, 1.f));
+        s.translate(Vec3(0.f, 0.f, -2.f));
+        setColour(s.material, 1.f, 1.f, 1.f, 16);
+        squares.push_back(s);
+    }
+    auto mirror = [](Square& s) { s.material.type = RT_MAT_MIRROR; s.material.reflectivity = 0.9f; };
+    { Square& s = squares[0]; s.material.materialScale = 4; mirror(s); }                                              /* back wall */
+    { Square& s = squares[1]; s.rotate_y(90); setColour(s.material, 1.f, .75f, .75f, 16); mirror(s); }                /* left wall */
+    { Square& s = squares[2]; s.rotate_y(-90); setColour(s.material, .75f, 1.f, .75f, 16); mirror(s); }               /* right wall */
+    { Square& s = squares[3]; s.rotate_x(-90); s.material.type = RT_MAT_CHECKER;                                      /* floor */
+      s.material.normalMap = loadImage("normalMaps/n3.ppm"); if (s.material.normalMap < 0) return false; }
+    { Square& s = squares[4]; s.rotate_x(90); mirror(s); }                                                            /* ceiling */
+    { Square& s = squares[5]; s.rotate_y(180); mirror(s); }                                                           /* front wall */
+    meshes.emplace_back();                                          /* Scene.h:698-711 */
+    Mesh& m = meshes.back();
+    if (!m.loadOFF(g_asset_dir + "/flamingo.off")) return false;
+    m.scale(Vec3(0.0125f));
+    m.translate(Vec3(0.f, -1.55f, 0.f));
+    m.build_arrays();
+    setColour(m.material, 1.f, 0.753f, 0.796f, 16);
+    m.material.transparency = 1.0f; m.material.index_medium = 1.2f;
     m.buildTree(3);
     buildSceneBvh();
     return true;
@@ -477,6 +558,7 @@ bool Scene::setup(const std::string& name) {
     if (name == "reflexion") return setup_reflexion_scene();
     if (name == "mesh_gorilla") return setup_mesh_scene("gorilla18_fixed.obj.off", false);
     if (name == "mesh_cow") return setup_mesh_scene("cow.off", true);
+    if (name == "reflexion_chamber") return setup_reflexion_chamber();
     if (name.rfind("soup:", 0) == 0) return setup_soup_scene(atoll(name.c_str() + 5));
     return false;
 }
@@ -486,6 +568,7 @@ static int32_t addMaterial(std::vector<rt_material>& out, const Material& m) {
     std::memset(&r, 0, sizeof(r));
     for (int k = 0; k < 3; k++) { r.ka[k] = m.ambient_material[k]; r.kd[k] = m.diffuse_material[k]; r.ks[k] = m.specular_material[k]; }
     r.shininess = m.shininess; r.type = m.type; r.ior = m.index_medium; r.transparency = m.transparency; r.reflectivity = m.reflectivity;
+    r.texture = m.texture + 1; r.normal_map = m.normalMap + 1; r.material_scale = m.materialScale;
     out.push_back(r);
     return (int32_t)out.size() - 1;
 }
@@ -537,6 +620,14 @@ const rt_scene_desc& Scene::flatten() {
     }
     rt_scene_desc& d = f_desc;
     std::memset(&d, 0, sizeof(d));
+    f_textures.clear();
+    for (const Image& img : textures) {
+        rt_texture t;
+        std::memset(&t, 0, sizeof(t));
+        t.width = img.width; t.height = img.height; t.channels = img.channels; t.texels = img.data.data();
+        f_textures.push_back(t);
+    }
+    d.n_textures = (int32_t)f_textures.size(); d.textures = f_textures.empty() ? nullptr : f_textures.data();
     d.n_materials = (int32_t)f_materials.size(); d.materials = f_materials.data();
     d.n_lights = (int32_t)f_lights.size(); d.lights = f_lights.data();
     d.n_squares = (int32_t)f_squares.size(); d.squares = f_squares.data();
@@ -605,6 +696,12 @@ extern "C" {
 rth_scene* rth_scene_new(void) { return new rth_scene(); }
 void rth_scene_free(rth_scene* s) { delete s; }
 void rth_set_asset_dir(const char* dir) { rth::set_asset_dir(dir); }
+void rth_set_image_dir(const char* dir) { rth::set_image_dir(dir); }
+int rth_add_texture(rth_scene* s, int width, int height, int channels, const uint8_t* texels) {
+    if (!s) return RT_ERR_ARG;
+    int idx = s->scene.addImage(width, height, channels, texels);
+    return idx < 0 ? RT_ERR_ARG : idx + 1;
+}
 int rth_scene_setup(rth_scene* s, const char* name) {
     if (!s || !name) return RT_ERR_ARG;
     return s->scene.setup(name) ? RT_OK : RT_ERR_ARG;
@@ -621,9 +718,15 @@ static rth::Material fromC(const rt_material* m) {
     r.diffuse_material = rth::Vec3(m->kd[0], m->kd[1], m->kd[2]);
     r.specular_material = rth::Vec3(m->ks[0], m->ks[1], m->ks[2]);
     r.shininess = m->shininess; r.type = m->type; r.index_medium = m->ior; r.transparency = m->transparency; r.reflectivity = m->reflectivity;
+    r.texture = m->texture - 1; r.normalMap = m->normal_map - 1; r.materialScale = m->material_scale == 0.0 ? 1.0 : m->material_scale;
     return r;
 }
+static bool imagesOk(const rth_scene* s, const rth::Material& m) {
+    const int n = (int)s->scene.textures.size();
+    return m.texture >= -1 && m.texture < n && m.normalMap >= -1 && m.normalMap < n;
+}
 int rth_add_square(rth_scene* s, const float verts[12], const rt_material* m) {
+    if (!s || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
     rth::Square q;
     for (int j = 0; j < 4; j++) q.vertices[j] = rth::Vec3(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]);
     q.material = fromC(m);
@@ -631,12 +734,13 @@ int rth_add_square(rth_scene* s, const float verts[12], const rt_material* m) {
     return RT_OK;
 }
 int rth_add_sphere(rth_scene* s, const float c[3], float radius, const rt_material* m) {
+    if (!s || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
     rth::Sphere sp; sp.m_center = rth::Vec3(c[0], c[1], c[2]); sp.m_radius = radius; sp.material = fromC(m);
     s->scene.spheres.push_back(sp);
     return RT_OK;
 }
 int rth_add_mesh(rth_scene* s, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt, const rt_material* m) {
-    if (nv <= 0 || nt <= 0) return RT_ERR_ARG;
+    if (!s || nv <= 0 || nt <= 0 || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
     for (int64_t i = 0; i < 3 * nt; i++) if (tris[i] >= (uint64_t)nv) return RT_ERR_ARG;
     s->scene.meshes.emplace_back();
     rth::Mesh& ms = s->scene.meshes.back();

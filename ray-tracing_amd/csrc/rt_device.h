@@ -54,14 +54,17 @@ __host__ __device__ inline uint32_t rt_rng_impl(uint32_t seed, uint32_t pixel, u
 }
 
 /* ---------------------------------------------------------------- device scene */
-struct DMat {              /* 64 B */
+struct DMat {              /* 80 B */
     float ka[3], kd[3], ks[3];
     float ior;
     double shininess;
     int32_t type;
     float transparency, reflectivity;
+    int32_t tex, nmap;     /* index into DScene::textures, -1 = none (hasTexture / hasNormalMap, Material.h:29-30) */
     int32_t pad;
+    double scale;          /* materialScale, Material.h:31 */
 };
+struct DTex { const uint8_t* data; int32_t w, h, ch, pad; };   /* stbi_load layout, Material.h:24-27 */
 struct DLight { float pos[3]; float radius; float color[3]; float pad; };
 struct DMesh {                 /* 48 B */
     int32_t root;              /* link of the tree's root */
@@ -86,6 +89,7 @@ struct DScene {
     const float4* squares;      /* 4 x float4: (bl,D) (right,|right|^2) (up,|up|^2) (n,material) */
     const float4* spheres;      /* 2 x float4: (center,radius) (material,-,-,-) */
     const DMat* mats;
+    const DTex* textures;
     const DLight* lights;
     const double* sincos;       /* sin[360], cos[360] of (float)k * degToRad, host libm (Scene.h:112-119) */
     int32_t n_lights, n_squares, n_spheres, n_meshes;
@@ -150,6 +154,23 @@ RT_DEV bool tri_test(const Ray& r, float4 q0, float4 q1, float4 q2, float4 q3, f
     t_out = len(sub(r.o, P));                                    /* Triangle.h:110 */
     w0 = u0; w1 = u1; w2 = u2;
     return true;
+}
+
+/* Material::getColorAt / getNormalAt, Material.h:86-104: nearest texel, % wrap, byte / 255.0 narrowed to float.
+ * u, v are never negative on the reference's primitives (there a negative index reads out of bounds); a negative
+ * remainder is wrapped into the image. */
+RT_DEV F3 texel_at(const DTex& t, double u, double v, double scale) {
+    int pu = (int)(u * (double)t.w * scale) % t.w;
+    int pv = (int)(v * (double)t.h * scale) % t.h;
+    if (pu < 0) pu += t.w;
+    if (pv < 0) pv += t.h;
+    const uint8_t* px = t.data + ((size_t)pv * (size_t)t.w + (size_t)pu) * (size_t)t.ch;
+    return f3((float)((double)px[0] / 255.0), (float)((double)px[1] / 255.0), (float)((double)px[2] / 255.0));
+}
+/* u, v of a sphere hit, Sphere.h:141-142: from the ray direction, double libm, narrowed where Scene.h:184 builds a Vec3 */
+RT_DEV void sphere_uv(F3 d, float& u, float& v) {
+    u = (float)(0.5 + (atan2((double)d.z, (double)d.x) / (2. * M_PI)));
+    v = (float)(0.5 + (asin((double)d.y) / M_PI));
 }
 
 /* Sphere::intersect, Sphere.h:86-146. */

@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(256) k_seed(const float* org, const float* dir
 /* Scene::rayTraceRecursive (Scene.h:174-280) for one path state: the recursion is unrolled into
  * child states carrying a throughput (radiance is linear in the child radiance, Scene.h:229,263-271). */
 __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
-                                                      uint32_t child_cap, DiffuseRec* drec, unsigned long long* dcode,
+                                                      uint32_t child_cap, DiffuseRec* drec, unsigned long long* dcode, uint32_t* dtex,
                                                       uint32_t diffuse_cap, Counters* ctr, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
     extern __shared__ int s_stack[];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,6 +447,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
     F3 c_o[2], c_d[2], c_thr[2];
     uint64_t c_code[2];
     DiffuseRec rec;
+    uint32_t rec_rgb = 0;
     uint32_t slot = 0, pixel = 0, sample = 0, flags = 0;
     uint64_t code = 0;
     int remaining = 0;
@@ -473,7 +474,30 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
         } else {
             DMat m = sc.mats[h.mat];
             uint32_t matword = (uint32_t)h.mat;
-            if (m.type == 3) {                                     /* checker: Material.h:153-161, Scene.h:51,192-197 */
+            if (m.tex >= 0 || m.nmap >= 0) {                       /* image texture / normal map, Scene.h:184-202 */
+                float uf = h.u, vf = h.v;
+                if (h.obj >= sc.n_squares && h.obj < sc.n_squares + sc.n_spheres) sphere_uv(r.d, uf, vf);
+                if (m.tex >= 0) {
+                    DTex t = sc.textures[m.tex];
+                    int pu = (int)((double)uf * (double)t.w * m.scale) % t.w, pv = (int)((double)vf * (double)t.h * m.scale) % t.h;
+                    if (pu < 0) pu += t.w;
+                    if (pv < 0) pv += t.h;
+                    const uint8_t* px = t.data + ((size_t)pv * (size_t)t.w + (size_t)pu) * (size_t)t.ch;
+                    rec_rgb = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+                    F3 col = f3((float)((double)px[0] / 255.0), (float)((double)px[1] / 255.0), (float)((double)px[2] / 255.0));
+                    for (int k = 0; k < 3; k++) { m.kd[k] = comp_at(col, k); m.ks[k] = comp_at(col, k); }
+                    matword |= 0x80000000u;                        /* k_shade takes kd = ks from the packed texel */
+                }
+                if (m.nmap >= 0) {                                 /* Material::applyTBN, Material.h:118-126: not remapped, not normalised */
+                    F3 nm = texel_at(sc.textures[m.nmap], (double)uf, (double)vf, m.scale);
+                    F3 tg = f3(1.f, 0.f, 0.f);
+                    F3 bt = cross(h.n, tg);
+                    h.n = f3(tg.x * nm.x + bt.x * nm.y + h.n.x * nm.z,      /* Mat3(t,b,n as columns) * nm, Vec3.h:156-163 */
+                             tg.y * nm.x + bt.y * nm.y + h.n.y * nm.z,
+                             tg.z * nm.x + bt.z * nm.y + h.n.z * nm.z);
+                }
+            }
+            if (m.type == 3 && m.tex < 0) {                        /* checker: Material.h:153-161, Scene.h:51,192-197 (a texture takes precedence) */
                 const float inv = (float)(1. / 3.f);
                 int xi = (int)floorf(inv * h.pos.x), yi = (int)floorf(inv * h.pos.y), zi = (int)floorf(inv * h.pos.z);
                 bool even = (xi + yi + zi) % 2 == 0;
@@ -554,6 +578,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
         q[2] = make_float4(rec.V[2], rec.thr[0], rec.thr[1], rec.thr[2]);
         q[3] = make_float4(__uint_as_float(rec.mat), __uint_as_float(rec.slot), __uint_as_float(rec.pixel), __uint_as_float(rec.sample));
         dcode[dbase] = code;
+        dtex[dbase] = rec_rgb;
     }
 }
 
@@ -586,6 +611,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
 #endif
 #ifndef RT_TRI_MORE
 #define RT_TRI_MORE 16        /* pending leaves that justify another triangle step in the same round */
+#endif
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 4     /* register budget of k_shadow: 128 VGPRs */
 #endif
 #ifndef RT_NODE_STEPS
 #define RT_NODE_STEPS 16      /* node-phase steps between two refill checks */
@@ -868,7 +896,7 @@ RT_DEV bool can_walk(const ShadowLane& s, int top_cap) {
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
 template <bool QUANT, bool COUNT>      /* COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
                                                         uint32_t* cnt, Counters* ctr, unsigned long long* next) {
     constexpr bool count_steps = COUNT;
     extern __shared__ int s_stack[];
@@ -977,7 +1005,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
 }
 
 /* Scene::phong (Scene.h:90-108) + the shadow factor of Scene.h:210-222. */
-__global__ void __launch_bounds__(256) k_shade(DScene sc, const DiffuseRec* __restrict__ drec, uint32_t n_rec, int S,
+__global__ void __launch_bounds__(256) k_shade(DScene sc, const DiffuseRec* __restrict__ drec, const uint32_t* __restrict__ dtex, uint32_t n_rec, int S,
                                                const uint32_t* __restrict__ cnt, long long* acc, uint32_t* nonfinite, Counters* ctr) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
@@ -988,6 +1016,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, const DiffuseRec* __re
     DMat m = sc.mats[matword & 0x00FFFFFFu];
     F3 ka = f3(m.ka[0], m.ka[1], m.ka[2]), kd = f3(m.kd[0], m.kd[1], m.kd[2]), ks = f3(m.ks[0], m.ks[1], m.ks[2]);
     if (matword & 0x40000000u) { float c = (matword & 0x20000000u) ? 1.f : 0.f; kd = f3s(c); ks = f3s(c); }
+    if (matword & 0x80000000u) {                                   /* texel of Material::getColorAt, Scene.h:189-191 */
+        uint32_t p = dtex[i];
+        kd = f3((float)((double)(p & 255u) / 255.0), (float)((double)((p >> 8) & 255u) / 255.0), (float)((double)((p >> 16) & 255u) / 255.0));
+        ks = kd;
+    }
     F3 color = f3s(0.f);
     float avg = 0.f;
     for (int li = 0; li < sc.n_lights; li++) {
@@ -1035,6 +1068,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene sc, const float* 
     o.pos[0] = h.pos.x; o.pos[1] = h.pos.y; o.pos[2] = h.pos.z;
     o.nrm[0] = h.n.x; o.nrm[1] = h.n.y; o.nrm[2] = h.n.z;
     o.u = h.u; o.v = h.v;
+    if (h.exists && h.obj >= sc.n_squares && h.obj < sc.n_squares + sc.n_spheres) sphere_uv(r.d, o.u, o.v);
     out[i] = o;
 }
 /* Scene::isInShadow on explicit (point, light) pairs (rt_occluded). */

@@ -54,7 +54,7 @@ struct rt_ctx {
     std::vector<TileD> tiles;
     unsigned long long queued_samples = 0;
 
-    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays;
+    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays, dtex;
     uint32_t batch = 1u << 20;
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
@@ -190,6 +190,7 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
     if ((rc = ensure(c, c->child, (size_t)2 * B * sizeof(PathState)))) return rc;
     if ((rc = ensure(c, c->drec, (size_t)B * sizeof(DiffuseRec)))) return rc;
     if ((rc = ensure(c, c->dcode, (size_t)B * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(c, c->dtex, (size_t)B * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->cnt, (size_t)B * std::max(L, 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->ctr, sizeof(Counters)))) return rc;
     if (!c->h_ctr) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
@@ -231,7 +232,7 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         HIP_TRY(c, hipEventRecord(e1->a, c->stream));
         hipLaunchKernelGGL(k_closest, dim3((nb + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, c->stream, c->sc, stack + base, nb,
                            static_cast<PathState*>(c->child.p), 2 * B, static_cast<DiffuseRec*>(c->drec.p),
-                           static_cast<unsigned long long*>(c->dcode.p), B, d_ctr, acc, nonfinite, prim);
+                           static_cast<unsigned long long*>(c->dcode.p), static_cast<uint32_t*>(c->dtex.p), B, d_ctr, acc, nonfinite, prim);
         HIP_TRY(c, hipEventRecord(e1->b, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -272,7 +273,7 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         if (n_diff) {
             if (L == 0) HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, 256, c->stream));
             hipLaunchKernelGGL(k_shade, dim3((n_diff + 255) / 256), dim3(256), 0, c->stream, c->sc, static_cast<const DiffuseRec*>(c->drec.p),
-                               n_diff, S, static_cast<const uint32_t*>(c->cnt.p), acc, nonfinite, d_ctr);
+                               static_cast<const uint32_t*>(c->dtex.p), n_diff, S, static_cast<const uint32_t*>(c->cnt.p), acc, nonfinite, d_ctr);
         }
         /* 4. push the children */
         if (n_child) {
@@ -414,6 +415,16 @@ const char* tree_defect(const rt_bvh_node* nodes, int64_t n_nodes, int32_t root,
 int check_desc(rt_ctx* c, const rt_scene_desc* d) {
     if (d->n_lights > RT_MAX_LIGHTS) return fail(c, RT_ERR_LIMIT, "more than %d lights", RT_MAX_LIGHTS);
     if (d->n_materials <= 0 && (d->n_squares + d->n_spheres + d->n_meshes) > 0) return fail(c, RT_ERR_ARG, "no materials");
+    if (d->n_textures < 0 || (d->n_textures > 0 && !d->textures)) return fail(c, RT_ERR_ARG, "textures");
+    for (int i = 0; i < d->n_textures; i++) {
+        const rt_texture& t = d->textures[i];
+        if (t.width <= 0 || t.height <= 0 || t.channels < 3 || !t.texels) return fail(c, RT_ERR_ARG, "texture %d: needs a size, >= 3 channels and texels", i);
+    }
+    for (int i = 0; i < d->n_materials; i++) {
+        const rt_material& m = d->materials[i];
+        if (m.texture < 0 || m.texture > d->n_textures || m.normal_map < 0 || m.normal_map > d->n_textures)
+            return fail(c, RT_ERR_ARG, "material %d: texture / normal map index out of range", i);
+    }
     if (d->top_depth > RT_MAX_TOP_DEPTH) return fail(c, RT_ERR_LIMIT, "top-level tree deeper than %d", RT_MAX_TOP_DEPTH);
     int n_obj = d->n_squares + d->n_spheres + d->n_meshes;
     auto link_ok = [](int32_t link, int64_t n_nodes, int64_t n_leaves) {
@@ -516,7 +527,7 @@ void rt_shutdown(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
-    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf, &c->srays}) release(*b);
+    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf, &c->srays, &c->dtex}) release(*b);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     for (EventPair& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     (void)hipEventDestroy(c->ev_frame_a);
@@ -638,6 +649,23 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         memset(&o, 0, sizeof(o));
         for (int k = 0; k < 3; k++) { o.ka[k] = m.ka[k]; o.kd[k] = m.kd[k]; o.ks[k] = m.ks[k]; }
         o.ior = m.ior; o.shininess = m.shininess; o.type = m.type; o.transparency = m.transparency; o.reflectivity = m.reflectivity;
+        o.tex = m.texture - 1; o.nmap = m.normal_map - 1;              /* 0 = none in the C-ABI */
+        o.scale = m.material_scale == 0.0 ? 1.0 : m.material_scale;
+    }
+    /* images: one texel buffer, a table of (pointer, size) records */
+    std::vector<uint8_t> texels;
+    std::vector<size_t> tex_off;
+    for (int i = 0; i < d->n_textures; i++) {
+        const rt_texture& t = d->textures[i];
+        tex_off.push_back(texels.size());
+        texels.insert(texels.end(), t.texels, t.texels + (size_t)t.width * t.height * t.channels);
+    }
+    const uint8_t* d_texels = nullptr;
+    if ((rc = upload(c, texels, &d_texels))) { free_scene(c); return rc; }
+    std::vector<DTex> textures((size_t)d->n_textures);
+    for (int i = 0; i < d->n_textures; i++) {
+        textures[i].data = d_texels + tex_off[i];
+        textures[i].w = d->textures[i].width; textures[i].h = d->textures[i].height; textures[i].ch = d->textures[i].channels; textures[i].pad = 0;
     }
     std::vector<DLight> lights((size_t)d->n_lights);
     for (int i = 0; i < d->n_lights; i++) {
@@ -668,6 +696,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         (rc = upload(c, qnodes, &sc.qnodes)) || (rc = upload(c, lbox, &sc.lbox)) ||
         (rc = upload(c, tnodes, &dtn)) || (rc = upload(c, tleaves, &sc.tleaves)) || (rc = upload(c, titems, &sc.titems)) ||
         (rc = upload(c, squares, &sc.squares)) || (rc = upload(c, spheres, &sc.spheres)) || (rc = upload(c, mats, &sc.mats)) ||
+        (rc = upload(c, textures, &sc.textures)) ||
         (rc = upload(c, lights, &sc.lights)) || (rc = upload(c, sincos, &sc.sincos))) {
         free_scene(c);
         return rc;

@@ -9,12 +9,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASSET_DIR = os.path.join(ROOT, "tests", "golden", "models")
+IMAGE_DIR = os.path.join(ROOT, "tests", "golden", "img")
 
 
 class Material(C.Structure):
     _fields_ = [("ka", C.c_float * 3), ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("pad0", C.c_float),
                 ("shininess", C.c_double), ("type", C.c_int32), ("ior", C.c_float),
-                ("transparency", C.c_float), ("reflectivity", C.c_float)]
+                ("transparency", C.c_float), ("reflectivity", C.c_float),
+                ("texture", C.c_int32), ("normal_map", C.c_int32), ("material_scale", C.c_double)]
 
 
 class Camera(C.Structure):
@@ -81,7 +83,12 @@ def lib():
         L.orc_rotmatrix.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_load_off.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                    C.POINTER(C.c_int)]
+        L.orc_set_image_dir.argtypes = [C.c_char_p]
+        L.orc_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_get_texture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+        L.orc_load_ppm.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int64]
         L.orc_set_asset_dir(ASSET_DIR.encode())
+        L.orc_set_image_dir(IMAGE_DIR.encode())
         _lib = L
     return _lib
 
@@ -101,6 +108,16 @@ def make_params(w, h, spp=1, max_depth=50, light_samples=35, shadow_mode=0, jitt
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def load_ppm(path):
+    """Binary PPM -> uint8 array (h, w, 3) through the oracle's reader."""
+    w, h = C.c_int(), C.c_int()
+    if lib().orc_load_ppm(path.encode(), C.byref(w), C.byref(h), None, 0) != 0:
+        raise RuntimeError(f"cannot read {path}")
+    px = np.zeros((h.value, w.value, 3), np.uint8)
+    assert lib().orc_load_ppm(path.encode(), C.byref(w), C.byref(h), _ptr(px), px.size) == 0
+    return px
 
 
 class Scene:
@@ -173,18 +190,37 @@ class Scene:
         c = np.asarray(color, np.float32)
         self.L.orc_add_light(self.h, _ptr(p), radius, _ptr(c))
 
+    def texture(self, i):
+        """Texel array (h, w, channels) of image i (0-based) of the scene."""
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        assert self.L.orc_get_texture(self.h, i, C.byref(w), C.byref(h), C.byref(ch), None) == 0
+        px = np.zeros((h.value, w.value, ch.value), np.uint8)
+        assert self.L.orc_get_texture(self.h, i, C.byref(w), C.byref(h), C.byref(ch), _ptr(px)) == 0
+        return px
+
+    def add_texture(self, texels):
+        """texels: uint8 array (h, w, channels>=3), rows top to bottom. Returns the value for Material.texture / normal_map."""
+        t = np.ascontiguousarray(texels, np.uint8)
+        idx = self.L.orc_add_texture(self.h, t.shape[1], t.shape[0], t.shape[2], _ptr(t))
+        if idx < 0:
+            raise RuntimeError("orc_add_texture failed")
+        return idx + 1
+
     def add_square(self, verts, mat):
         v = np.ascontiguousarray(verts, np.float32).reshape(12)
-        self.L.orc_add_square(self.h, _ptr(v), C.byref(mat))
+        if self.L.orc_add_square(self.h, _ptr(v), C.byref(mat)) != 0:
+            raise RuntimeError("orc_add_square failed")
 
     def add_sphere(self, center, radius, mat):
         c = np.asarray(center, np.float32)
-        self.L.orc_add_sphere(self.h, _ptr(c), radius, C.byref(mat))
+        if self.L.orc_add_sphere(self.h, _ptr(c), radius, C.byref(mat)) != 0:
+            raise RuntimeError("orc_add_sphere failed")
 
     def add_mesh(self, verts, tris, mat):
         v = np.ascontiguousarray(verts, np.float32)
         t = np.ascontiguousarray(tris, np.uint32)
-        self.L.orc_add_mesh(self.h, _ptr(v), len(v), _ptr(t), len(t), C.byref(mat))
+        if self.L.orc_add_mesh(self.h, _ptr(v), len(v), _ptr(t), len(t), C.byref(mat)) != 0:
+            raise RuntimeError("orc_add_mesh failed")
 
     def intersect(self, org, dirs):
         org = np.ascontiguousarray(org, np.float32)

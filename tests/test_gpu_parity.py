@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): hit identities (object ordinal, triangle index)
 also t / position / normal bit-exact; radiance max |delta| <= 1/255 on the 8-bit output
 (PSNR >= 50 dB for stochastic soft-shadow configs).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +14,7 @@ from helpers import psnr
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["final", "refraction", "reflexion", "mesh_gorilla", "mesh_cow", "soup:20000"]
+SCENES = ["final", "refraction", "reflexion", "reflexion_chamber", "mesh_gorilla", "mesh_cow", "soup:20000"]
 _cache = {}
 
 
@@ -140,7 +142,8 @@ def test_ray_trace_radiance(rt, ctx, name, shadow_mode):
 
 
 @pytest.mark.parametrize("name,w,h,spp,depth", [("final", 64, 64, 2, 50), ("refraction", 160, 90, 4, 5),
-                                                 ("mesh_gorilla", 128, 72, 2, 50), ("soup:20000", 96, 54, 4, 5)])
+                                                 ("mesh_gorilla", 128, 72, 2, 50), ("soup:20000", 96, 54, 4, 5),
+                                                 ("reflexion_chamber", 80, 80, 2, 12)])
 def test_render_frame(rt, ctx, name, w, h, spp, depth):
     hs, os_ = scene_pair(rt, ctx, name)
     aspect = w / h
@@ -285,6 +288,65 @@ def test_free_form_scene_and_edge_cases(rt, ctx):
     o = os_.trace(org, dirs, O.make_params(48, 48, spp=1))
     radiance_check(g, o, "free-form")
     assert np.isnan(o).any(), "the degenerate triangle should poison some normals"
+
+
+def test_image_textures_and_normal_maps(rt, ctx):
+    """Material::getColorAt / getNormalAt / applyTBN (Material.h:86-126, Scene.h:184-202) on every primitive kind and
+    material type: textured diffuse / mirror / glass spheres (u,v from the ray direction), a floor with texture, normal
+    map and materialScale 3, a textured + normal-mapped mesh, a 4-channel image."""
+    s4 = O.load_ppm(os.path.join(O.IMAGE_DIR, "sphereTextures", "s4.ppm"))
+    n3 = O.load_ppm(os.path.join(O.IMAGE_DIR, "normalMaps", "n3.ppm"))
+    rgba = np.random.default_rng(5).integers(0, 256, (29, 37, 4)).astype(np.uint8)
+    hs, os_ = rt.HostScene(), O.Scene()
+    quad = np.array([[-4, -1.5, 2], [4, -1.5, 2], [4, -1.5, -6], [-4, -1.5, -6]], np.float32)
+    mv = np.array([[-3, -1.5, -5], [3, -1.5, -5], [3, 2.5, -5.5], [-3, 2.5, -5.5]], np.float32)
+    mt = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    for s, M in ((hs, rt), (os_, O)):
+        t_s4, t_n3, t_rgba = s.add_texture(s4), s.add_texture(n3), s.add_texture(rgba)
+
+        def mat(**kw):
+            m = M.Material()
+            m.kd[:] = kw.get("kd", [0.7, 0.7, 0.7])
+            m.ks[:] = kw.get("ks", [0.4, 0.4, 0.4])
+            m.shininess = 12.0
+            m.type = kw.get("type", 0)
+            m.ior = kw.get("ior", 1.0)
+            m.transparency = kw.get("transparency", 0.0)
+            m.reflectivity = kw.get("reflectivity", 0.0)
+            m.texture = kw.get("texture", 0)
+            m.normal_map = kw.get("normal_map", 0)
+            m.material_scale = kw.get("scale", 1.0)
+            return m
+        s.add_light([1.5, 3.0, 1.0], 0.3)
+        s.add_light([-2.0, 2.0, 0.5], 0.0)
+        s.add_square(quad, mat(texture=t_s4, normal_map=t_n3, scale=3.0))
+        s.add_sphere([-1.6, -0.6, -2.5], 0.9, mat(texture=t_s4))
+        s.add_sphere([0.3, -0.7, -3.2], 0.8, mat(type=2, reflectivity=0.8, texture=t_rgba))
+        s.add_sphere([1.7, -0.5, -2.2], 0.7, mat(type=1, ior=1.3, transparency=0.6, texture=t_s4, scale=2.0))
+        s.add_sphere([0.0, 1.2, -3.0], 0.5, mat(type=3, normal_map=t_n3))
+        s.add_mesh(mv, mt, mat(texture=t_rgba, normal_map=t_n3, scale=5.0))
+        s.build(3, 12)
+    ctx.upload_scene(hs)
+    oc = O.default_camera(1.0, zoom=0.0, z=-1.0)
+    org, dirs = O.camera_rays(oc, O.make_params(72, 72, spp=1), 0, 0, 72, 72)
+    gh, oh = ctx.intersect(org, dirs), os_.intersect(org, dirs)
+    assert_hits_equal(gh, oh, "textured")
+    kinds = set(oh["obj"][oh["exists"] == 1].tolist())
+    assert {0, 1, 2, 3, 4, 5} <= kinds, f"every object should be seen, got {kinds}"
+    for shadow_mode in (1, 0):
+        g = ctx.trace(org, dirs, rt.make_params(72, 72, spp=1, jitter=0, max_depth=8, shadow_mode=shadow_mode))
+        o = os_.trace(org, dirs, O.make_params(72, 72, spp=1, max_depth=8, shadow_mode=shadow_mode))
+        radiance_check(g, o, f"textured mode {shadow_mode}")
+    assert np.unique(O.quantize(o).reshape(-1, 3), axis=0).shape[0] > 500, "the textures should show"
+    # a material that points past the texture table is refused at upload
+    dp = hs.desc
+    dp.contents.materials[0].texture = 9
+    c2 = rt.Context(0)
+    try:
+        with pytest.raises(rt.RtError, match="texture"):
+            c2._check(c2.L.rt_upload_scene(c2.h, dp), "rt_upload_scene")
+    finally:
+        c2.close()
 
 
 def test_call_order_and_limits(rt):

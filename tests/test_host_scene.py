@@ -39,7 +39,11 @@ def compare_scene(hs, os_):
     def mat_eq(i, om):
         m = mats[i]
         return (list(m.kd) == list(om.kd) and list(m.ks) == list(om.ks) and list(m.ka) == list(om.ka) and m.shininess == om.shininess
-                and m.type == om.type and m.ior == om.ior and m.transparency == om.transparency and m.reflectivity == om.reflectivity)
+                and m.type == om.type and m.ior == om.ior and m.transparency == om.transparency and m.reflectivity == om.reflectivity
+                and m.texture == om.texture and m.normal_map == om.normal_map and m.material_scale == om.material_scale)
+
+    for i, t in enumerate(A["textures"]):
+        assert np.array_equal(t, os_.texture(i))
 
     for i, s in enumerate(A["squares"]):
         v, om = os_.square(i)
@@ -69,7 +73,7 @@ def compare_scene(hs, os_):
         assert sorted(it.tolist()) == list(range(m.tri_count)), "every triangle sits in exactly one leaf"
 
 
-@pytest.mark.parametrize("name,depth", [("final", 12), ("final", 3), ("refraction", 12), ("reflexion", 12), ("mesh_gorilla", 12),
+@pytest.mark.parametrize("name,depth", [("final", 12), ("final", 3), ("refraction", 12), ("reflexion", 12), ("reflexion_chamber", 12), ("mesh_gorilla", 12),
                                         ("mesh_cow", 16), ("soup:30000", 12), ("soup:30000", 20)])
 def test_named_scenes_flatten_like_the_oracle(rt, name, depth):
     compare_scene(rt.HostScene(name, 3, depth), O.Scene(name, 3, depth))
@@ -93,6 +97,36 @@ def test_free_form_scene_and_top_depth(rt):
         s.build(6, 9)
     compare_scene(hs, os_)
     assert hs.desc.contents.top_depth <= 6
+
+
+def test_ppm_images_and_texture_tables(rt):
+    """The host's PPM reader, the oracle's and PIL agree on the reference's image data; the chamber scene carries its
+    normal map; texture indices are 1-based in the C-ABI (0 = none) and checked."""
+    from PIL import Image
+    path = os.path.join(O.IMAGE_DIR, "sphereTextures", "s4.ppm")
+    ref = np.array(Image.open(path))
+    assert ref.shape == (256, 512, 3) and np.array_equal(O.load_ppm(path), ref)
+    hs, os_ = rt.HostScene("reflexion_chamber", 3, 12), O.Scene("reflexion_chamber", 3, 12)
+    A = hs.arrays()
+    nm = np.array(Image.open(os.path.join(O.IMAGE_DIR, "normalMaps", "n3.ppm")))
+    assert len(A["textures"]) == 1 and np.array_equal(A["textures"][0], nm) and np.array_equal(os_.texture(0), nm)
+    floor = A["materials"][A["squares"][3].material]
+    assert floor.normal_map == 1 and floor.texture == 0 and floor.type == 3 and floor.material_scale == 1.0
+    assert A["materials"][A["squares"][0].material].material_scale == 4.0
+    hs2, os2 = rt.HostScene(), O.Scene()
+    for s, M in ((hs2, rt), (os2, O)):
+        t = s.add_texture(ref)
+        assert t == 1
+        mat = M.Material()
+        mat.texture = 2                                   # no such image
+        with pytest.raises(RuntimeError):
+            s.add_sphere([0, 0, 0], 1.0, mat)
+        mat.texture = t
+        s.add_sphere([0, 0, 0], 1.0, mat)
+        s.build(3, 12)
+    compare_scene(hs2, os2)
+    with pytest.raises((RuntimeError, rt.RtError)):
+        hs2.add_texture(ref[:, :, :2])                    # fewer than 3 channels
 
 
 def test_load_off_matches_the_oracle(rt):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Side measurements on the BASELINE configs that bench.py does not quote.
 
-    python tools/bench_configs.py C1|C2|C3|C4|C4cow [--steps K] [--spp N] [--depth D]
+    python tools/bench_configs.py C1|C2|C3|C4|C4cow|chamber [--steps K] [--spp N] [--depth D] [--ppm out.ppm]
 
 One JSON line: ms/frame, Mrays/s split by ray class, time inside the two traversal kernels.
 bench.py stays the C5 line the driver reads; the numbers printed here go into DESIGN.md.
@@ -23,6 +23,8 @@ CONFIGS = {
     "C3": ("refraction", 3, 12, 1920, 1080, 30, 5),
     "C4": ("mesh_gorilla", 3, 12, 1920, 1080, 30, 50),
     "C4cow": ("mesh_cow", 3, 12, 1920, 1080, 30, 50),
+    # the normal-mapped mirror chamber (Scene.h:601-714) at the reference's window size and literals
+    "chamber": ("reflexion_chamber", 3, 12, 480, 480, 30, 50),
 }
 
 
@@ -33,6 +35,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--depth", type=int, default=0)
+    ap.add_argument("--ppm", default="", help="also write the frame as a P3 file (main.cpp:245-255)")
     args = ap.parse_args()
     import torch
     if not torch.cuda.is_available():
@@ -79,6 +82,8 @@ def main():
         "kernel_ms_per_frame": {"k_shadow": round(tot["ms_shadow"] / k, 2), "k_closest": round(tot["ms_closest"] / k, 2)},
         "frame_checksum": float(frame.double().sum().item()),
     }), flush=True)
+    if args.ppm:
+        rt.write_ppm(args.ppm, frame.cpu().numpy())
     ctx.close()
 
 
