@@ -596,15 +596,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
 #define TRI_NONE 0xFFFFFFFFu
 #define ST_IDLE 0
 #define ST_TOP 1
-#define ST_MESH 2
+#define ST_MESH 2             /* inside a mesh tree with a step to take */
+#define ST_BLOCKED 3          /* inside a mesh tree, waiting for its pending leaf to be tested (see can_walk) */
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 8       /* refill once this many lanes are idle */
 #endif
 #ifndef RT_GRAB
 #define RT_GRAB 512u           /* rays a wave takes from the global counter at a time */
-#endif
-#ifndef RT_DEFER
-#define RT_DEFER 1            /* keep walking with one leaf pending (fuller triangle rounds) */
 #endif
 #ifndef RT_TRI_MIN
 #define RT_TRI_MIN 24         /* pending leaves that make a triangle round worthwhile */
@@ -707,6 +705,14 @@ RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int st
         }
     }
 }
+/* A lane inside a mesh can take a node step unless a pending leaf blocks it: with a leaf pending it may still
+ * visit nodes and pop, but not take on a second leaf (the cursor then keeps that leaf's link) and not leave the
+ * mesh. Without a pending leaf every cursor value has a step to take (a leaf link -- e.g. a mesh that is one
+ * leaf -- becomes pending, an exhausted walk returns to the top level). */
+RT_DEV bool can_walk(const ShadowLane& s, int top_cap) {   /* decides between ST_MESH and ST_BLOCKED after every step */
+    if (s.tri_pos == TRI_NONE) return true;
+    return s.link >= 0 || (s.link == LINK_NONE && s.msp > top_cap);
+}
 /* one traversal unit inside a mesh tree for a lane with no pending triangle: pop if the cursor is
  * empty, then either fetch a leaf's triangle range or process one inner node (two slab tests) and
  * move to the next link straight away */
@@ -735,17 +741,19 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
         else link = LINK_NONE;
     }
     /* a leaf: its triangles become pending; with one leaf pending already the lane keeps the link and is blocked */
-    if (link < 0 && link != LINK_NONE && (!RT_DEFER || s.tri_pos == TRI_NONE)) {
+    if (link < 0 && link != LINK_NONE && s.tri_pos == TRI_NONE) {
         s.tri_pos = leaf_first(link);
         link = LINK_NONE;
     }
     s.link = link;
+    if (!can_walk(s, sc.top_cap)) s.st = ST_BLOCKED;
 }
 RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     const float4* q = sc.tri + 4 * (size_t)s.tri_pos;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     s.tri_pos = __float_as_uint(q2.w) != 0u ? TRI_NONE : s.tri_pos + 1;
-    if (RT_DEFER && s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link); s.link = LINK_NONE; }   /* the blocked leaf is next */
+    if (s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link); s.link = LINK_NONE; }   /* the blocked leaf is next */
+    s.st = can_walk(s, sc.top_cap) ? ST_MESH : ST_BLOCKED;
     float t, w0, w1, w2;
     if (tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
@@ -823,11 +831,12 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, int* stk, int str
         else if (s.msp > sc.top_cap) link = stk[lds_index(--s.msp, stride)];
         else link = LINK_NONE;
     }
-    if (link < 0 && link != LINK_NONE && (!RT_DEFER || s.tri_pos == TRI_NONE)) {
+    if (link < 0 && link != LINK_NONE && s.tri_pos == TRI_NONE) {
         s.tri_pos = leaf_first(link) | TRI_NEW;
         link = LINK_NONE;
     }
     s.link = link;
+    if (!can_walk(s, sc.top_cap)) s.st = ST_BLOCKED;
 }
 /* one triangle of a leaf of the quantised walk; the first one brings the reference's test of the leaf's own box along */
 RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
@@ -842,7 +851,8 @@ RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt
         reached = slab(s.r, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tEnter) && !(tEnter > s.prune_t);
     }
     s.tri_pos = (!reached || __float_as_uint(q2.w) != 0u) ? TRI_NONE : pos + 1;
-    if (RT_DEFER && s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link) | TRI_NEW; s.link = LINK_NONE; }
+    if (s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link) | TRI_NEW; s.link = LINK_NONE; }
+    s.st = can_walk(s, sc.top_cap) ? ST_MESH : ST_BLOCKED;
     float t, w0, w1, w2;
     if (reached && tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
@@ -885,14 +895,6 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
     rays[2 * idx + 1] = make_float4(d.x, d.y, d.z, 0.f);
 }
 
-/* A lane inside a mesh can take a node step unless a pending leaf blocks it: with a leaf pending it may still
- * visit nodes and pop, but not take on a second leaf (the cursor then keeps that leaf's link) and not leave the
- * mesh. Without a pending leaf every cursor value has a step to take (a leaf link -- e.g. a mesh that is one
- * leaf -- becomes pending, an exhausted walk returns to the top level). */
-RT_DEV bool can_walk(const ShadowLane& s, int top_cap) {
-    if (s.tri_pos == TRI_NONE) return true;
-    return s.link >= 0 || (s.link == LINK_NONE && s.msp > top_cap);
-}
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
 template <bool QUANT, bool COUNT>      /* COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
@@ -961,11 +963,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         /* node phase */
 #pragma unroll 1
         for (int k = 0; k < RT_NODE_STEPS; k++) {
-            /* a lane walks while it has a node to visit or something to pop; with RT_DEFER it may do so with one leaf
-             * pending, and is blocked (waiting) only by a second leaf or when nothing is left but the pending leaf */
-            const bool pend = s.tri_pos != TRI_NONE;
-            bool walking = s.st == ST_MESH && (RT_DEFER ? can_walk(s, sc.top_cap) : !pend);
-            bool waiting = s.st == ST_MESH && !walking;
+            /* a lane walks while it has a node to visit or something to pop, also with one leaf pending; it is
+             * blocked only by a second leaf or when nothing is left but the pending leaf */
+            const bool walking = s.st == ST_MESH, waiting = s.st == ST_BLOCKED;
             unsigned long long mw = __builtin_amdgcn_ballot_w64(walking), mt = __builtin_amdgcn_ballot_w64(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wn++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
@@ -973,22 +973,18 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_nodeph += k_t1 - k_t0; k_t0 = k_t1; }
         /* triangle phase: worth a round once enough lanes have a leaf pending, or when the walkers are the minority */
-        if (RT_DEFER) {
-            const bool pend = s.st == ST_MESH && s.tri_pos != TRI_NONE;
-            const bool canwalk = s.st == ST_MESH && can_walk(s, sc.top_cap);
-            const int np = __popcll(__builtin_amdgcn_ballot_w64(pend)), nw = __popcll(__builtin_amdgcn_ballot_w64(canwalk));
-            const int nb = __popcll(__builtin_amdgcn_ballot_w64(pend && !canwalk));
+        {
+            const bool pend = s.st >= ST_MESH && s.tri_pos != TRI_NONE;
+            const int np = __popcll(__builtin_amdgcn_ballot_w64(pend)), nw = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_MESH));
+            const int nb = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_BLOCKED));
             if (np < RT_TRI_MIN && nw > nb && nw > 0) continue;
         }
 #pragma unroll 1
         for (int k = 0; k < RT_TRI_STEPS; k++) {
-            bool pending = s.st == ST_MESH && s.tri_pos != TRI_NONE;
+            bool pending = s.st >= ST_MESH && s.tri_pos != TRI_NONE;
             const int np = __popcll(__builtin_amdgcn_ballot_w64(pending));
             if (np == 0) break;
-            if (RT_DEFER && k > 0 && np < RT_TRI_MORE) {      /* a thin follow-up round only if nobody could walk instead */
-                const bool canwalk = s.st == ST_MESH && can_walk(s, sc.top_cap);
-                if (__builtin_amdgcn_ballot_w64(canwalk) != 0ull) break;
-            }
+            if (k > 0 && np < RT_TRI_MORE && __builtin_amdgcn_ballot_w64(s.st == ST_MESH) != 0ull) break;   /* a thin follow-up round only if nobody could walk instead */
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wt++; if (pending) c_tri++; }
             if (pending) { if (QUANT) shadow_quant_tri_step(sc, s, cnt); else shadow_tri_step(sc, s, cnt); }
         }
