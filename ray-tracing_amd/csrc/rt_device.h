@@ -75,13 +75,15 @@ struct DMesh {                 /* 48 B */
     int32_t pad[2];
 };
 
+#define RT_TRI_STRIDE 8
 struct DScene {
-    const float4* tri;          /* 4 x float4 per triangle, leaf order: (c0,D) (c1,area) (c2,last-in-leaf flag) (n,-) */
+    const float4* tri;          /* RT_TRI_STRIDE x float4 (one 128-byte line) per triangle, leaf order: (c0,D) (c1,area) (c2,last-in-leaf
+                                 * flag) (n,-), then for the first record of a leaf the reference box of that leaf (min.xyz,max.x)
+                                 * (max.yz,-,-) -- a shadow ray's leaf visit is one cache line -- and two spare slots */
     const uint4* tri_ids;       /* (v0, v1, v2 global vertex ids, index into Mesh::triangles), leaf order */
     const float* normals;       /* 3 per vertex */
     const float4* mnodes;       /* 4 x float4 per inner node; child links encoded as in rt_kernels.h (LINK_*) */
     const uint4* qnodes;        /* shadow walk: the same nodes in 32 bytes, child boxes rounded outward to 16-bit planes */
-    const float4* lbox;         /* 2 x float4 per triangle slot: the reference box of the leaf that starts at this record */
     const DMesh* meshes;
     const float4* tnodes;
     const uint2* tleaves;

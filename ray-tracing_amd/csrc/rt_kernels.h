@@ -108,7 +108,7 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
         } else {
             uint32_t g = leaf_first(link);
             for (bool last = false; !last; g++) {
-                const float4* q = sc.tri + 4 * (size_t)g;
+                const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)g;
                 float4 q2 = q[2];
                 last = __float_as_uint(q2.w) != 0u;
                 float t, w0, w1, w2;
@@ -150,7 +150,7 @@ RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound
         } else {
             uint32_t g = leaf_first(link);
             for (bool last = false; !last; g++) {
-                const float4* q = sc.tri + 4 * (size_t)g;
+                const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)g;
                 float4 q2 = q[2];
                 last = __float_as_uint(q2.w) != 0u;
                 float t, w0, w1, w2;
@@ -749,7 +749,7 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
     if (!can_walk(s, sc.top_cap)) s.st = ST_BLOCKED;
 }
 RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
-    const float4* q = sc.tri + 4 * (size_t)s.tri_pos;
+    const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)s.tri_pos;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     s.tri_pos = __float_as_uint(q2.w) != 0u ? TRI_NONE : s.tri_pos + 1;
     if (s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link); s.link = LINK_NONE; }   /* the blocked leaf is next */
@@ -779,7 +779,7 @@ RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
  * between this form on the padded planes and the reference's (plane - o)*inv on the true ones
  * (below 1e-6 * M * |inv| in total). v_max3/v_min3 drop NaN operands, which only loosens the test.
  * A leaf is then entered only if the reference's own test (slab()) passes on the leaf's reference
- * box (DScene::lbox), and its triangles are tested exactly as before: bit-identical occlusion. */
+ * box (slots 4-5 of the leaf's first triangle record), and its triangles are tested exactly as before: bit-identical occlusion. */
 #define TRI_NEW 0x80000000u
 RT_DEV void quant_setup(ShadowLane& s, const DMesh& m) {
     const Ray& r = s.r;
@@ -841,12 +841,11 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, int* stk, int str
 /* one triangle of a leaf of the quantised walk; the first one brings the reference's test of the leaf's own box along */
 RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     const uint32_t pos = s.tri_pos & ~TRI_NEW;
-    const float4* q = sc.tri + 4 * (size_t)pos;
+    const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)pos;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     bool reached = true;
     if (s.tri_pos & TRI_NEW) {
-        const float4* bx = sc.lbox + 2 * (size_t)pos;
-        float4 b0 = bx[0], b1 = bx[1];
+        float4 b0 = q[4], b1 = q[5];                               /* the leaf's reference box rides in the same line */
         float tEnter;
         reached = slab(s.r, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tEnter) && !(tEnter > s.prune_t);
     }

@@ -312,12 +312,12 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
 /* ---- quantised shadow nodes (see rt_kernels.h). Every child box of a mesh tree is rounded OUTWARD to
  * 16-bit planes in the frame (qmin, qstep) of the mesh, one extra quantum of padding on each side, and
  * stored with the two links in 32 bytes: x,y,z of the left box as lo | hi << 16, then the right box,
- * then the links. A child without triangles gets lo = 65535, hi = 0 (never entered). lbox receives
- * the exact box of every leaf. Returns false if the boxes cannot be used this way: a non-finite or
+ * then the links. A child without triangles gets lo = 65535, hi = 0 (never entered). The first triangle
+ * record of every leaf receives the leaf's exact box (slots 4-5 of its 128-byte line). Returns false if the boxes cannot be used this way: a non-finite or
  * inverted box, or a child box that is not inside its parent's box (then "leaf box hit => every box
  * above it hit" does not hold and the exact walk is used instead). */
 bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<rt_bvh_node>& nodes, int32_t empty_link, DMesh& dm,
-                   std::vector<uint4>& qnodes, std::vector<float4>& lbox) {
+                   std::vector<uint4>& qnodes, std::vector<float4>& lbox /* = the triangle records */) {
     double gmin[3] = {INFINITY, INFINITY, INFINITY}, gmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t v = 0; v < m.vert_count; v++)
         for (int k = 0; k < 3; k++) {
@@ -349,8 +349,8 @@ bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<r
     };
     auto leaf_box = [&](int32_t link, const float* mn, const float* mx) {
         size_t first = (size_t)(-2 - (int64_t)link);
-        lbox[2 * first] = make_float4(mn[0], mn[1], mn[2], mx[0]);
-        lbox[2 * first + 1] = make_float4(mx[1], mx[2], 0.f, 0.f);
+        lbox[RT_TRI_STRIDE * first + 4] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+        lbox[RT_TRI_STRIDE * first + 5] = make_float4(mx[1], mx[2], 0.f, 0.f);
     };
     const float ninf[3] = {-INFINITY, -INFINITY, -INFINITY}, pinf[3] = {INFINITY, INFINITY, INFINITY};
     const int32_t groot = nodes.empty() || m.root < 0 ? -1 : (int32_t)(m.root + m.node_first);
@@ -546,17 +546,16 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     DScene sc{};
 
     /* triangles in leaf order with the per-test quantities of Triangle.h precomputed */
-    std::vector<float4> tri(((size_t)d->n_tris + 1) * 4, make_float4(0.f, 0.f, 0.f, 0.f));   /* +1: the record empty leaves point at */
+    std::vector<float4> tri(((size_t)d->n_tris + 1) * RT_TRI_STRIDE, make_float4(0.f, 0.f, 0.f, 0.f));   /* +1: the record empty leaves point at */
     {
         uint32_t one = 1u;
-        memcpy(&tri[4 * (size_t)d->n_tris + 2].w, &one, 4);
+        memcpy(&tri[RT_TRI_STRIDE * (size_t)d->n_tris + 2].w, &one, 4);
     }
     std::vector<uint4> ids((size_t)d->n_tris);
     std::vector<rt_bvh_node> nodes(d->mesh_nodes, d->mesh_nodes + d->n_mesh_nodes);
     std::vector<DMesh> meshes((size_t)d->n_meshes);
     /* shadow walk (rt_kernels.h, "quantised shadow nodes"): 32-byte copies of the nodes + the exact box of every leaf */
     std::vector<uint4> qnodes((size_t)d->n_mesh_nodes * 2, make_uint4(0u, 0u, 0u, 0u));
-    std::vector<float4> lbox(((size_t)d->n_tris + 1) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
     bool quant_ok = true;
     int max_mesh_depth = 0;
     for (int mi = 0; mi < d->n_meshes; mi++) {
@@ -581,10 +580,10 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
             float area = norm / 2.f;
             float D = hdot(c0, n);                                 /* Triangle.h:58 */
             size_t g = (size_t)(m.tri_first + j);
-            tri[4 * g + 0] = make_float4(c0.x, c0.y, c0.z, D);
-            tri[4 * g + 1] = make_float4(c1.x, c1.y, c1.z, area);
-            tri[4 * g + 2] = make_float4(c2.x, c2.y, c2.z, 0.f);
-            tri[4 * g + 3] = make_float4(n.x, n.y, n.z, 0.f);
+            tri[RT_TRI_STRIDE * g + 0] = make_float4(c0.x, c0.y, c0.z, D);
+            tri[RT_TRI_STRIDE * g + 1] = make_float4(c1.x, c1.y, c1.z, area);
+            tri[RT_TRI_STRIDE * g + 2] = make_float4(c2.x, c2.y, c2.z, 0.f);
+            tri[RT_TRI_STRIDE * g + 3] = make_float4(n.x, n.y, n.z, 0.f);
             ids[g] = make_uint4((uint32_t)(m.vert_first + iv[0]), (uint32_t)(m.vert_first + iv[1]), (uint32_t)(m.vert_first + iv[2]), t);
         }
         auto glob = [&](int32_t link) {
@@ -601,7 +600,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
             const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + i];
             if (lf.count) {
                 uint32_t one = 1u;
-                memcpy(&tri[4 * (size_t)(m.tri_first + lf.first + lf.count - 1) + 2].w, &one, 4);
+                memcpy(&tri[RT_TRI_STRIDE * (size_t)(m.tri_first + lf.first + lf.count - 1) + 2].w, &one, 4);
             }
         }
         meshes[mi].root = glob(m.root);
@@ -611,7 +610,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         meshes[mi].delta = 8e-4f * amax + 1e-5f;
         meshes[mi].amax = amax;
         meshes[mi].pad[0] = meshes[mi].pad[1] = 0;
-        quant_ok = quantise_mesh(d, m, nodes, (int32_t)(-2 - d->n_tris), meshes[mi], qnodes, lbox) && quant_ok;
+        quant_ok = quantise_mesh(d, m, nodes, (int32_t)(-2 - d->n_tris), meshes[mi], qnodes, tri) && quant_ok;
     }
     if (d->n_verts > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "too many vertices");
     std::vector<float> normals(d->normals, d->normals + 3 * d->n_verts);
@@ -693,7 +692,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     const rt_bvh_node* dtn = nullptr;
     if ((rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
         (rc = upload(c, nodes, &dn)) || (rc = upload(c, meshes, &sc.meshes)) ||
-        (rc = upload(c, qnodes, &sc.qnodes)) || (rc = upload(c, lbox, &sc.lbox)) ||
+        (rc = upload(c, qnodes, &sc.qnodes)) ||
         (rc = upload(c, tnodes, &dtn)) || (rc = upload(c, tleaves, &sc.tleaves)) || (rc = upload(c, titems, &sc.titems)) ||
         (rc = upload(c, squares, &sc.squares)) || (rc = upload(c, spheres, &sc.spheres)) || (rc = upload(c, mats, &sc.mats)) ||
         (rc = upload(c, textures, &sc.textures)) ||
