@@ -99,6 +99,11 @@ struct DScene {
     int32_t top_cap;            /* stack entries reserved for the top level */
     int32_t stack_cap;          /* total per-lane stack entries */
     int32_t quant_ok;           /* all mesh boxes are finite and nested: the 32-byte shadow nodes may be used */
+    /* the top-level tables once more, packed into one blob that k_shadow copies into LDS when it is small:
+     * byte offsets of tnodes, tleaves, titems, squares, spheres, meshes inside top_blob */
+    const float4* top_blob;
+    int32_t top_blob_bytes;
+    int32_t top_off[6];
 };
 
 struct Ray { F3 o, d, inv; };

@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_seed(const float* org, const float* dir
 __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
                                                       uint32_t child_cap, DiffuseRec* drec, unsigned long long* dcode, uint32_t* dtex,
                                                       uint32_t diffuse_cap, Counters* ctr, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
-    extern __shared__ int s_stack[];
+    extern __shared__ __align__(16) int s_stack[];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n;
     int* stk = s_stack + threadIdx.x;
@@ -654,23 +654,26 @@ RT_DEV void shadow_on_hit(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     if (s.visited == 0) { shadow_finish(s, true, cnt); return; }
     shadow_restart(sc, s, 1, s.visited);
 }
+/* the top-level tables as k_shadow reads them: in global memory, or its LDS copy (generic pointers) */
+struct TopTables { const float4* tnodes; const uint2* tleaves; const uint32_t* titems; const float4* squares; const float4* spheres; const DMesh* meshes; };
+#define RT_TOP_LDS_MAX 2048
 /* top-level state machine: runs until the ray ends or enters a mesh tree */
 RT_DEV void quant_setup(ShadowLane& s, const DMesh& m);
 template <bool QUANT>
-RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int stride, uint32_t* cnt) {
+RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane& s, int* stk, int stride, uint32_t* cnt) {
     for (;;) {
         if (s.top_pos < s.top_end) {
-            int ord = (int)sc.titems[s.top_pos++];
+            int ord = (int)tt.titems[s.top_pos++];
             if (ord < sc.n_squares) {
-                const float4* q = sc.squares + 4 * ord;
+                const float4* q = tt.squares + 4 * ord;
                 float t, u, v;
                 if (square_test(s.r, q[0], q[1], q[2], q[3], t, u, v) && t <= s.bound) { shadow_on_hit(sc, s, cnt); if (s.st == ST_IDLE) return; }
             } else if (ord < sc.n_squares + sc.n_spheres) {
-                const float4* q = sc.spheres + 2 * (ord - sc.n_squares);
+                const float4* q = tt.spheres + 2 * (ord - sc.n_squares);
                 float t; F3 n;
                 if (sphere_test(s.r, q[0], t, n) && t <= s.bound) { shadow_on_hit(sc, s, cnt); if (s.st == ST_IDLE) return; }
             } else {
-                DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
+                DMesh m = tt.meshes[ord - sc.n_squares - sc.n_spheres];
                 /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter > bound*1.00002 + slack is
                  * still conservative and costs one compare per child */
                 s.prune_t = s.mode == 0 ? s.bound * 1.00002f + prune_slack(s.r, m.delta) : INFINITY;
@@ -687,7 +690,7 @@ RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int st
             s.tlink = stk[lds_index(--s.tsp, stride)];
         }
         if (s.tlink >= 0) {
-            const float4* nd = sc.tnodes + 4 * (size_t)s.tlink;
+            const float4* nd = tt.tnodes + 4 * (size_t)s.tlink;
             float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
             float tL, tR;
             bool hL = slab(s.r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
@@ -699,7 +702,7 @@ RT_DEV void shadow_advance_top(const DScene& sc, ShadowLane& s, int* stk, int st
             else s.tlink = LINK_NONE;
         } else {
             if (s.mode == 1 && s.visited >= s.limit) { shadow_finish(s, true, cnt); return; }
-            uint2 lf = sc.tleaves[-1 - s.tlink];
+            uint2 lf = tt.tleaves[-1 - s.tlink];
             s.top_pos = lf.x; s.top_end = lf.x + lf.y; s.leaf_open = 1;
             s.tlink = LINK_NONE;
         }
@@ -898,14 +901,30 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
 template <bool QUANT, bool COUNT>      /* COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
-                                                        uint32_t* cnt, Counters* ctr, unsigned long long* next) {
+                                                        uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds) {
     constexpr bool count_steps = COUNT;
-    extern __shared__ int s_stack[];
+    extern __shared__ __align__(16) int s_stack[];
     unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0, c_wn = 0, c_wt = 0, c_wtop = 0, c_ltop = 0;
     int* stk = s_stack + threadIdx.x;
     constexpr int stride = RT_BLOCK;        /* the host always launches RT_BLOCK-lane blocks */
     const int lane = __lane_id();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    TopTables tt;
+    {
+        const char* base = reinterpret_cast<const char*>(sc.top_blob);
+        if (top_lds) {                                  /* one wave per block: copy, then everybody reads the LDS copy */
+            float4* dst = reinterpret_cast<float4*>(s_stack + sc.stack_cap * RT_BLOCK);
+            for (int i = lane; i < sc.top_blob_bytes / 16; i += RT_BLOCK) dst[i] = sc.top_blob[i];
+            __syncthreads();
+            base = reinterpret_cast<const char*>(dst);
+        }
+        tt.tnodes = reinterpret_cast<const float4*>(base + sc.top_off[0]);
+        tt.tleaves = reinterpret_cast<const uint2*>(base + sc.top_off[1]);
+        tt.titems = reinterpret_cast<const uint32_t*>(base + sc.top_off[2]);
+        tt.squares = reinterpret_cast<const float4*>(base + sc.top_off[3]);
+        tt.spheres = reinterpret_cast<const float4*>(base + sc.top_off[4]);
+        tt.meshes = reinterpret_cast<const DMesh*>(base + sc.top_off[5]);
+    }
     ShadowLane s;
     s.st = ST_IDLE;
     s.tri_pos = TRI_NONE;
@@ -957,7 +976,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             continue;
         }
         if (count_steps) { if (s.st == ST_TOP) c_ltop++; k_t1 = __builtin_readcyclecounter(); k_refill += k_t1 - k_t0; k_t0 = k_t1; }
-        if (s.st == ST_TOP) shadow_advance_top<QUANT>(sc, s, stk, stride, cnt);
+        if (s.st == ST_TOP) shadow_advance_top<QUANT>(sc, tt, s, stk, stride, cnt);
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_top += k_t1 - k_t0; k_t0 = k_t1; }
         /* node phase */
 #pragma unroll 1
@@ -1053,7 +1072,7 @@ __global__ void __launch_bounds__(256) k_resolve(const long long* acc, const uin
 /* Scene::computeIntersection on explicit rays (rt_intersect). */
 struct HitOut { int32_t exists, obj, tri; float t; float pos[3]; float nrm[3]; float u, v; };
 __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene sc, const float* org, const float* dir, uint32_t n, HitOut* out) {
-    extern __shared__ int s_stack[];
+    extern __shared__ __align__(16) int s_stack[];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r = make_ray(f3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), f3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
@@ -1068,7 +1087,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene sc, const float* 
 }
 /* Scene::isInShadow on explicit (point, light) pairs (rt_occluded). */
 __global__ void __launch_bounds__(RT_BLOCK) k_occluded(DScene sc, const float* pts, const float* lp, uint32_t n, int32_t* out) {
-    extern __shared__ int s_stack[];
+    extern __shared__ __align__(16) int s_stack[];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool o = in_shadow(sc, f3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), f3(lp[3 * i], lp[3 * i + 1], lp[3 * i + 2]),

@@ -261,9 +261,12 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
                 HIP_TRY(c, hipEventRecord(e2->a, c->stream));
                 uint32_t* cnt0 = static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L;
+                /* small top-level tables (a few objects) are copied into LDS behind the stacks: a new ray walks them
+                 * through four dependent loads while the other lanes of its wave wait */
+                const int top_lds = (c->sc.top_blob_bytes <= RT_TOP_LDS_MAX && !getenv("RT_TOP_GLOBAL")) ? 1 : 0;
                 auto launch = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds, c->stream, c->sc, static_cast<const float4*>(c->srays.p),
-                                       threads, S, cnt0, d_ctr, &d_ctr->work);
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, c->sc,
+                                       static_cast<const float4*>(c->srays.p), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds);
                 };
                 if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<true, true>); else launch(k_shadow<true, false>); }
                 else { if (c->count_steps) launch(k_shadow<false, true>); else launch(k_shadow<false, false>); }
@@ -702,6 +705,28 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     }
     sc.mnodes = reinterpret_cast<const float4*>(dn);
     sc.tnodes = reinterpret_cast<const float4*>(dtn);
+    {   /* the same top-level tables as one blob (16-byte aligned sections) for k_shadow's LDS copy */
+        std::vector<uint8_t> blob;
+        auto section = [&](const void* p, size_t bytes, int k) {
+            blob.resize((blob.size() + 15) & ~(size_t)15);
+            sc.top_off[k] = (int32_t)blob.size();
+            const uint8_t* b = static_cast<const uint8_t*>(p);
+            blob.insert(blob.end(), b, b + bytes);
+        };
+        std::vector<uint2> tl = tleaves;
+        if (tl.empty()) tl.push_back(make_uint2(0, 0));
+        section(tnodes.data(), tnodes.size() * sizeof(rt_bvh_node), 0);
+        section(tl.data(), tl.size() * sizeof(uint2), 1);
+        section(titems.data(), titems.size() * sizeof(uint32_t), 2);
+        section(squares.data(), squares.size() * sizeof(float4), 3);
+        section(spheres.data(), spheres.size() * sizeof(float4), 4);
+        section(meshes.data(), meshes.size() * sizeof(DMesh), 5);
+        blob.resize((blob.size() + 15) & ~(size_t)15);
+        const uint8_t* db = nullptr;
+        if ((rc = upload(c, blob, &db))) { free_scene(c); return rc; }
+        sc.top_blob = reinterpret_cast<const float4*>(db);
+        sc.top_blob_bytes = (int32_t)blob.size();
+    }
     sc.n_lights = d->n_lights; sc.n_squares = d->n_squares; sc.n_spheres = d->n_spheres; sc.n_meshes = d->n_meshes;
     sc.top_root = (d->n_squares + d->n_spheres + d->n_meshes) > 0 ? d->top_root : -1;
     if ((d->n_squares + d->n_spheres + d->n_meshes) == 0) {
