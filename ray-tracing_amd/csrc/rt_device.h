@@ -71,8 +71,9 @@ struct DMesh {                 /* 48 B */
     int32_t material;
     float delta;               /* see prune_slack() */
     float amax;                /* largest |coordinate| of the mesh's vertices */
-    float qmin[3], qstep[3];   /* frame of the 16-bit box planes in DScene::qnodes: plane = qmin + q*qstep */
-    int32_t pad[2];
+    float qmin[3], qstep[3];   /* frame of the 16-bit box planes in DScene::qnodes / wnodes: plane = qmin + q*qstep */
+    int32_t wroot;             /* link of the 4-wide shadow tree's root */
+    int32_t pad;
 };
 
 #define RT_TRI_STRIDE 8
@@ -83,7 +84,8 @@ struct DScene {
     const uint4* tri_ids;       /* (v0, v1, v2 global vertex ids, index into Mesh::triangles), leaf order */
     const float* normals;       /* 3 per vertex */
     const float4* mnodes;       /* 4 x float4 per inner node; child links encoded as in rt_kernels.h (LINK_*) */
-    const uint4* qnodes;        /* shadow walk: the same nodes in 32 bytes, child boxes rounded outward to 16-bit planes */
+    const uint4* qnodes;        /* the mesh nodes in 32 bytes, child boxes rounded outward to 16-bit planes (upload-time intermediate) */
+    const uint4* wnodes;        /* shadow walk: 4-wide nodes folded from qnodes, 64 bytes: 4 x (x,y,z plane pairs), 4 links */
     const DMesh* meshes;
     const float4* tnodes;
     const uint2* tleaves;
@@ -98,6 +100,7 @@ struct DScene {
     int32_t top_root;
     int32_t top_cap;            /* stack entries reserved for the top level */
     int32_t stack_cap;          /* total per-lane stack entries */
+    int32_t wstack_cap;         /* per-lane stack entries the 4-wide shadow walk can need (three pending links per level) */
     int32_t quant_ok;           /* all mesh boxes are finite and nested: the 32-byte shadow nodes may be used */
     /* the top-level tables once more, packed into one blob that k_shadow copies into LDS when it is small:
      * byte offsets of tnodes, tleaves, titems, squares, spheres, meshes inside top_blob */

@@ -677,7 +677,7 @@ RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane
                 /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter > bound*1.00002 + slack is
                  * still conservative and costs one compare per child */
                 s.prune_t = s.mode == 0 ? s.bound * 1.00002f + prune_slack(s.r, m.delta) : INFINITY;
-                s.link = m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
+                s.link = QUANT ? m.wroot : m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
                 if (QUANT) quant_setup(s, m);
                 s.st = ST_MESH;
                 return;
@@ -811,27 +811,48 @@ RT_DEV float quant_entry(uint32_t wx, uint32_t wy, uint32_t wz, const ShadowLane
     hit = tMin <= tMax;
     return tMin;
 }
-RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, int* stk, int stride) {
+/* The 4-wide walk can have three links pending per level. Only the first lds_cap entries of a lane's stack
+ * live in LDS (what keeps 16 waves on a CU); deeper ones -- rare -- go to a per-lane slice of global memory,
+ * entry k of lane l of block b at ovf[(b*ovf_cap + k)*64 + l]. */
+struct WideStack { int* lds; int* ovf; int lds_cap; };
+RT_DEV void wpush(const WideStack& w, int& sp, int link) {
+    if (sp < w.lds_cap) w.lds[sp * RT_BLOCK] = link; else w.ovf[(sp - w.lds_cap) * RT_BLOCK] = link;
+    sp++;
+}
+RT_DEV int wpop(const WideStack& w, int& sp) {
+    --sp;
+    return sp < w.lds_cap ? w.lds[sp * RT_BLOCK] : w.ovf[(sp - w.lds_cap) * RT_BLOCK];
+}
+/* one 4-wide node (64 bytes: twelve packed plane pairs, four links): the nearest hit child next, the others pushed */
+RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& w) {
     int link = s.link;
     if (link == LINK_NONE) {
         if (s.msp == sc.top_cap) { s.st = ST_TOP; return; }        /* mesh done without a hit: next object of the leaf */
-        link = stk[lds_index(--s.msp, stride)];
+        link = wpop(w, s.msp);
     }
     if (link >= 0) {
-        const uint4* nd = sc.qnodes + 2 * (size_t)link;
-        uint4 a = nd[0], b = nd[1];
+        const uint4* nd = sc.wnodes + 4 * (size_t)link;
+        uint4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
         const float lim = fminf(100.0f, s.prune_t);                  /* tMax of AABB::intersect; beyond prune_t nothing can matter */
-        bool hL, hR;
-        float tL = quant_entry(a.x, a.y, a.z, s, lim, hL);
-        float tR = quant_entry(a.w, b.x, b.y, s, lim, hR);
-        int left = (int)b.z, right = (int)b.w;
-        bool nearLeft = tL <= tR;
-        if (hL && hR) {
-            stk[lds_index(s.msp++, stride)] = nearLeft ? right : left;
-            link = nearLeft ? left : right;
-        } else if (hL) link = left;
-        else if (hR) link = right;
-        else if (s.msp > sc.top_cap) link = stk[lds_index(--s.msp, stride)];
+        bool h0, h1, h2, h3;
+        float t0 = quant_entry(a.x, a.y, a.z, s, lim, h0);
+        float t1 = quant_entry(a.w, b.x, b.y, s, lim, h1);
+        float t2 = quant_entry(b.z, b.w, c.x, s, lim, h2);
+        float t3 = quant_entry(c.y, c.z, c.w, s, lim, h3);
+        const int l0 = (int)d.x, l1 = (int)d.y, l2 = (int)d.z, l3 = (int)d.w;
+        /* nearest hit child first (an occluder is usually found early that way); the order of the rest is free */
+        t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
+        float ta = t0; int la = l0, ia = 0;
+        if (t1 < ta) { ta = t1; la = l1; ia = 1; }
+        if (t2 < ta) { ta = t2; la = l2; ia = 2; }
+        if (t3 < ta) { ta = t3; la = l3; ia = 3; }
+        if (h0 || h1 || h2 || h3) {
+            if (h0 && ia != 0) wpush(w, s.msp, l0);
+            if (h1 && ia != 1) wpush(w, s.msp, l1);
+            if (h2 && ia != 2) wpush(w, s.msp, l2);
+            if (h3 && ia != 3) wpush(w, s.msp, l3);
+            link = la;
+        } else if (s.msp > sc.top_cap) link = wpop(w, s.msp);
         else link = LINK_NONE;
     }
     if (link < 0 && link != LINK_NONE && s.tri_pos == TRI_NONE) {
@@ -901,7 +922,8 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
 template <bool QUANT, bool COUNT>      /* COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
-                                                        uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds) {
+                                                        uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds,
+                                                        int* ovf, int lds_cap, int ovf_cap) {
     constexpr bool count_steps = COUNT;
     extern __shared__ __align__(16) int s_stack[];
     unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0, c_wn = 0, c_wt = 0, c_wtop = 0, c_ltop = 0;
@@ -909,11 +931,14 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     constexpr int stride = RT_BLOCK;        /* the host always launches RT_BLOCK-lane blocks */
     const int lane = __lane_id();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    WideStack wst;
+    wst.lds = stk; wst.lds_cap = lds_cap;
+    wst.ovf = ovf + ((size_t)blockIdx.x * ovf_cap) * RT_BLOCK + threadIdx.x;
     TopTables tt;
     {
         const char* base = reinterpret_cast<const char*>(sc.top_blob);
         if (top_lds) {                                  /* one wave per block: copy, then everybody reads the LDS copy */
-            float4* dst = reinterpret_cast<float4*>(s_stack + sc.stack_cap * RT_BLOCK);
+            float4* dst = reinterpret_cast<float4*>(s_stack + lds_cap * RT_BLOCK);
             for (int i = lane; i < sc.top_blob_bytes / 16; i += RT_BLOCK) dst[i] = sc.top_blob[i];
             __syncthreads();
             base = reinterpret_cast<const char*>(dst);
@@ -987,7 +1012,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             unsigned long long mw = __builtin_amdgcn_ballot_w64(walking), mt = __builtin_amdgcn_ballot_w64(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wn++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
-            if (walking) { if (QUANT) shadow_quant_step(sc, s, stk, stride); else shadow_node_step(sc, s, stk, stride); }
+            if (walking) { if (QUANT) shadow_quant_step(sc, s, wst); else shadow_node_step(sc, s, stk, stride); }
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_nodeph += k_t1 - k_t0; k_t0 = k_t1; }
         /* triangle phase: worth a round once enough lanes have a leaf pending, or when the walkers are the minority */

@@ -54,7 +54,7 @@ struct rt_ctx {
     std::vector<TileD> tiles;
     unsigned long long queued_samples = 0;
 
-    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays, dtex;
+    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays, dtex, ovf;
     uint32_t batch = 1u << 20;
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
@@ -264,9 +264,15 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 /* small top-level tables (a few objects) are copied into LDS behind the stacks: a new ray walks them
                  * through four dependent loads while the other lanes of its wave wait */
                 const int top_lds = (c->sc.top_blob_bytes <= RT_TOP_LDS_MAX && !getenv("RT_TOP_GLOBAL")) ? 1 : 0;
+                /* stack entries of a lane kept in LDS (the first stack_cap = what the binary walks need; the 4-wide shadow walk
+                 * can need three per level and spills the rest -- rare -- to a global slice) */
+                const int lds_cap = c->sc.stack_cap;
+                const int ovf_cap = c->sc.quant_ok ? std::max(0, c->sc.wstack_cap - lds_cap) : 0;
+                if ((rc = ensure(c, c->ovf, std::max<size_t>(256, (size_t)blocks * ovf_cap * RT_BLOCK * sizeof(int))))) return rc;
                 auto launch = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, c->sc,
-                                       static_cast<const float4*>(c->srays.p), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds);
+                                       static_cast<const float4*>(c->srays.p), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds,
+                                       static_cast<int*>(c->ovf.p), lds_cap, ovf_cap);
                 };
                 if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<true, true>); else launch(k_shadow<true, false>); }
                 else { if (c->count_steps) launch(k_shadow<false, true>); else launch(k_shadow<false, false>); }
@@ -393,6 +399,69 @@ bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<r
     }
     return ok;
 }
+
+
+/* ---- 4-wide shadow tree: every other level of the (quantised) binary tree folded away. A wide node takes a
+ * binary node's two children and keeps replacing the largest inner one by its own two children until four
+ * slots are filled; children without triangles are dropped. 64 bytes: twelve packed plane pairs
+ * (child-major: c0.x c0.y c0.z c1.x ...), four links; an unused slot has lo = 65535, hi = 0 and LINK_NONE.
+ * The boxes are the binary tree's own quantised boxes, so everything said about them still holds. */
+struct WideFold {
+    const std::vector<uint4>& q;       /* 2 uint4 per binary node, links global */
+    int32_t empty_link;
+    const float* qstep;
+    std::vector<uint4>& out;           /* 4 uint4 per wide node */
+    int depth = 0;
+    struct Cand { int32_t link; uint32_t w[3]; };
+    void children(int32_t node, Cand* c, int& n) const {
+        const uint4 a = q[2 * (size_t)node], b = q[2 * (size_t)node + 1];
+        Cand l = {(int32_t)b.z, {a.x, a.y, a.z}}, r = {(int32_t)b.w, {a.w, b.x, b.y}};
+        n = 0;
+        if (l.link != empty_link) c[n++] = l;
+        if (r.link != empty_link) c[n++] = r;
+    }
+    float area(const Cand& c) const {
+        float e[3];
+        for (int k = 0; k < 3; k++) e[k] = ((float)(c.w[k] >> 16) - (float)(c.w[k] & 0xFFFFu)) * qstep[k];
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    }
+    int32_t build(int32_t node, int level) {
+        Cand cand[4];
+        int n = 0;
+        children(node, cand, n);
+        while (n > 0 && n < 4) {
+            int pick = -1;
+            float best = -1.f;
+            for (int i = 0; i < n; i++)
+                if (cand[i].link >= 0) { float a = area(cand[i]); if (a > best) { best = a; pick = i; } }
+            if (pick < 0) break;
+            Cand sub[2];
+            int m = 0;
+            children(cand[pick].link, sub, m);
+            for (int i = pick; i + 1 < n; i++) cand[i] = cand[i + 1];
+            n--;
+            for (int i = 0; i < m; i++) cand[n++] = sub[i];
+        }
+        if (n == 0) return LINK_NONE;
+        const size_t w = out.size() / 4;
+        out.resize(out.size() + 4, make_uint4(0u, 0u, 0u, 0u));
+        depth = std::max(depth, level + 1);
+        uint32_t words[16];
+        for (int i = 0; i < 12; i++) words[i] = 65535u;
+        for (int i = 12; i < 16; i++) words[i] = (uint32_t)LINK_NONE;
+        int used = 0;
+        for (int i = 0; i < n; i++) {
+            int32_t link = cand[i].link;
+            if (link >= 0) { link = build(link, level + 1); if (link == LINK_NONE) continue; }
+            for (int k = 0; k < 3; k++) words[3 * used + k] = cand[i].w[k];
+            words[12 + used] = (uint32_t)link;
+            used++;
+        }
+        if (used == 0) { out.resize(4 * w); return LINK_NONE; }
+        for (int r = 0; r < 4; r++) out[4 * w + r] = make_uint4(words[4 * r], words[4 * r + 1], words[4 * r + 2], words[4 * r + 3]);
+        return (int32_t)w;
+    }
+};
 
 /* The links must form a tree no deeper than declared: the device stacks are sized by the declared depth
  * and the kernels loop until the links run out, so a cycle or a shared child would never end.
@@ -530,7 +599,7 @@ void rt_shutdown(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
-    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf, &c->srays, &c->dtex}) release(*b);
+    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf, &c->srays, &c->dtex, &c->ovf}) release(*b);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     for (EventPair& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     (void)hipEventDestroy(c->ev_frame_a);
@@ -559,8 +628,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     std::vector<DMesh> meshes((size_t)d->n_meshes);
     /* shadow walk (rt_kernels.h, "quantised shadow nodes"): 32-byte copies of the nodes + the exact box of every leaf */
     std::vector<uint4> qnodes((size_t)d->n_mesh_nodes * 2, make_uint4(0u, 0u, 0u, 0u));
+    std::vector<uint4> wnodes;                                              /* 4-wide shadow tree, all meshes */
     bool quant_ok = true;
-    int max_mesh_depth = 0;
+    int max_mesh_depth = 0, max_wide_depth = 0;
     for (int mi = 0; mi < d->n_meshes; mi++) {
         const rt_mesh& m = d->meshes[mi];
         max_mesh_depth = std::max(max_mesh_depth, m.depth);
@@ -612,8 +682,14 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         for (int64_t v = 0; v < 3 * m.vert_count; v++) amax = std::max(amax, std::fabs(d->positions[3 * m.vert_first + v]));
         meshes[mi].delta = 8e-4f * amax + 1e-5f;
         meshes[mi].amax = amax;
-        meshes[mi].pad[0] = meshes[mi].pad[1] = 0;
+        meshes[mi].pad = 0; meshes[mi].wroot = LINK_NONE;
         quant_ok = quantise_mesh(d, m, nodes, (int32_t)(-2 - d->n_tris), meshes[mi], qnodes, tri) && quant_ok;
+        {
+            WideFold wf{qnodes, (int32_t)(-2 - d->n_tris), meshes[mi].qstep, wnodes};
+            if (meshes[mi].root >= 0) meshes[mi].wroot = wf.build(meshes[mi].root, 0);
+            else meshes[mi].wroot = meshes[mi].root == wf.empty_link ? LINK_NONE : meshes[mi].root;
+            max_wide_depth = std::max(max_wide_depth, wf.depth);
+        }
     }
     if (d->n_verts > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "too many vertices");
     std::vector<float> normals(d->normals, d->normals + 3 * d->n_verts);
@@ -695,7 +771,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     const rt_bvh_node* dtn = nullptr;
     if ((rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
         (rc = upload(c, nodes, &dn)) || (rc = upload(c, meshes, &sc.meshes)) ||
-        (rc = upload(c, qnodes, &sc.qnodes)) ||
+        (rc = upload(c, qnodes, &sc.qnodes)) || (rc = upload(c, wnodes, &sc.wnodes)) ||
         (rc = upload(c, tnodes, &dtn)) || (rc = upload(c, tleaves, &sc.tleaves)) || (rc = upload(c, titems, &sc.titems)) ||
         (rc = upload(c, squares, &sc.squares)) || (rc = upload(c, spheres, &sc.spheres)) || (rc = upload(c, mats, &sc.mats)) ||
         (rc = upload(c, textures, &sc.textures)) ||
@@ -736,6 +812,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     }
     sc.top_cap = d->top_depth + 2;
     sc.stack_cap = sc.top_cap + max_mesh_depth + 2;
+    sc.wstack_cap = sc.top_cap + 3 * max_wide_depth + 2;
     sc.quant_ok = (quant_ok && !getenv("RT_SHADOW_EXACT_NODES")) ? 1 : 0;
     if (c->debug) fprintf(stderr, "[rtgpu] scene: %lld mesh nodes, depth %d, quantised shadow nodes %s\n", (long long)d->n_mesh_nodes, max_mesh_depth,
                           sc.quant_ok ? "on" : "off");
