@@ -823,12 +823,13 @@ RT_DEV int wpop(const WideStack& w, int& sp) {
     --sp;
     return sp < w.lds_cap ? w.lds[sp * RT_BLOCK] : w.ovf[(sp - w.lds_cap) * RT_BLOCK];
 }
-/* one 4-wide node (64 bytes: twelve packed plane pairs, four links): the nearest hit child next, the others pushed */
+/* one 4-wide node (64 bytes: twelve packed plane pairs, four links): the nearest hit child next, the others pushed.
+ * Stack traffic stays in LDS unless this step could cross lds_cap (then, and only then, the spilling push/pop run). */
 RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& w) {
     int link = s.link;
     if (link == LINK_NONE) {
         if (s.msp == sc.top_cap) { s.st = ST_TOP; return; }        /* mesh done without a hit: next object of the leaf */
-        link = wpop(w, s.msp);
+        link = s.msp <= w.lds_cap ? w.lds[--s.msp * RT_BLOCK] : wpop(w, s.msp);
     }
     if (link >= 0) {
         const uint4* nd = sc.wnodes + 4 * (size_t)link;
@@ -846,13 +847,23 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
         if (t1 < ta) { ta = t1; la = l1; ia = 1; }
         if (t2 < ta) { ta = t2; la = l2; ia = 2; }
         if (t3 < ta) { ta = t3; la = l3; ia = 3; }
+        const bool p0 = h0 && ia != 0, p1 = h1 && ia != 1, p2 = h2 && ia != 2, p3 = h3 && ia != 3;
         if (h0 || h1 || h2 || h3) {
-            if (h0 && ia != 0) wpush(w, s.msp, l0);
-            if (h1 && ia != 1) wpush(w, s.msp, l1);
-            if (h2 && ia != 2) wpush(w, s.msp, l2);
-            if (h3 && ia != 3) wpush(w, s.msp, l3);
+            if (s.msp + 3 <= w.lds_cap) {                             /* the common case: no entry of this step can leave LDS */
+                int* top = w.lds + s.msp * RT_BLOCK;
+                if (p0) { *top = l0; top += RT_BLOCK; }
+                if (p1) { *top = l1; top += RT_BLOCK; }
+                if (p2) { *top = l2; top += RT_BLOCK; }
+                if (p3) { *top = l3; }
+                s.msp += (int)p0 + (int)p1 + (int)p2 + (int)p3;
+            } else {
+                if (p0) wpush(w, s.msp, l0);
+                if (p1) wpush(w, s.msp, l1);
+                if (p2) wpush(w, s.msp, l2);
+                if (p3) wpush(w, s.msp, l3);
+            }
             link = la;
-        } else if (s.msp > sc.top_cap) link = wpop(w, s.msp);
+        } else if (s.msp > sc.top_cap) link = s.msp <= w.lds_cap ? w.lds[--s.msp * RT_BLOCK] : wpop(w, s.msp);
         else link = LINK_NONE;
     }
     if (link < 0 && link != LINK_NONE && s.tri_pos == TRI_NONE) {

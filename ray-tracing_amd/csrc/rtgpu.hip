@@ -266,7 +266,9 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 const int top_lds = (c->sc.top_blob_bytes <= RT_TOP_LDS_MAX && !getenv("RT_TOP_GLOBAL")) ? 1 : 0;
                 /* stack entries of a lane kept in LDS (the first stack_cap = what the binary walks need; the 4-wide shadow walk
                  * can need three per level and spills the rest -- rare -- to a global slice) */
-                const int lds_cap = c->sc.stack_cap;
+                int lds_cap = c->sc.stack_cap;
+                if (const char* e = getenv("RT_WIDE_LDS_CAP"))          /* test knob: force the spilling path */
+                    if (c->sc.quant_ok && atoi(e) > 0) lds_cap = std::max(c->sc.top_cap + 1, std::min(lds_cap, atoi(e)));
                 const int ovf_cap = c->sc.quant_ok ? std::max(0, c->sc.wstack_cap - lds_cap) : 0;
                 if ((rc = ensure(c, c->ovf, std::max<size_t>(256, (size_t)blocks * ovf_cap * RT_BLOCK * sizeof(int))))) return rc;
                 auto launch = [&](auto kern) {

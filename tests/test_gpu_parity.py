@@ -218,6 +218,16 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
     monkeypatch.delenv("RT_SHADOW_EXACT_NODES")
     assert np.array_equal(bits(quant), bits(exact)) and np.array_equal(qprim, eprim)
     assert qst.rays_shadow == est.rays_shadow
+    # almost no LDS stack: the 4-wide walk spills its pending links to global memory
+    monkeypatch.setenv("RT_WIDE_LDS_CAP", "1")
+    c4 = rt.Context(0)
+    try:
+        c4.upload_scene(hs)
+        spilled, sprim, sst = c4.render(cam, p)
+    finally:
+        c4.close()
+    monkeypatch.delenv("RT_WIDE_LDS_CAP")
+    assert np.array_equal(bits(spilled), bits(quant)) and sst.rays_shadow == qst.rays_shadow
     # shrink one child box of a mesh root below its own children's boxes: not nested any more
     dp = hs.desc
     d = dp.contents
