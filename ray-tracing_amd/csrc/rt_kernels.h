@@ -610,6 +610,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
 #ifndef RT_TRI_MORE
 #define RT_TRI_MORE 16        /* pending leaves that justify another triangle step in the same round */
 #endif
+#ifndef RT_CHILD_ORDER
+#define RT_CHILD_ORDER 0      /* 4-wide walk: 0 = first hit child in slot order next, 1 = nearest hit child next (see shadow_quant_step) */
+#endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4     /* register budget of k_shadow: 128 VGPRs */
 #endif
@@ -842,11 +845,16 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
         float t3 = quant_entry(c.y, c.z, c.w, s, lim, h3);
         const int l0 = (int)d.x, l1 = (int)d.y, l2 = (int)d.z, l3 = (int)d.w;
         /* nearest hit child first (an occluder is usually found early that way); the order of the rest is free */
+#if RT_CHILD_ORDER == 0
+        int la = h0 ? l0 : h1 ? l1 : h2 ? l2 : l3, ia = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+        (void)t0; (void)t1; (void)t2; (void)t3;
+#else
         t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
         float ta = t0; int la = l0, ia = 0;
         if (t1 < ta) { ta = t1; la = l1; ia = 1; }
         if (t2 < ta) { ta = t2; la = l2; ia = 2; }
         if (t3 < ta) { ta = t3; la = l3; ia = 3; }
+#endif
         const bool p0 = h0 && ia != 0, p1 = h1 && ia != 1, p2 = h2 && ia != 2, p3 = h3 && ia != 3;
         if (h0 || h1 || h2 || h3) {
             if (s.msp + 3 <= w.lds_cap) {                             /* the common case: no entry of this step can leave LDS */
