@@ -71,7 +71,7 @@ struct DMesh {                 /* 48 B */
     int32_t material;
     float delta;               /* see prune_slack() */
     float amax;                /* largest |coordinate| of the mesh's vertices */
-    float qmin[3], qstep[3];   /* frame of the 16-bit box planes in DScene::qnodes / wnodes: plane = qmin + q*qstep */
+    float qmin[3], qstep[3];   /* frame of the 16-bit box planes in DScene::wnodes: plane = qmin + q*qstep */
     int32_t wroot;             /* link of the 4-wide shadow tree's root */
     int32_t pad;
 };
@@ -84,8 +84,7 @@ struct DScene {
     const uint4* tri_ids;       /* (v0, v1, v2 global vertex ids, index into Mesh::triangles), leaf order */
     const float* normals;       /* 3 per vertex */
     const float4* mnodes;       /* 4 x float4 per inner node; child links encoded as in rt_kernels.h (LINK_*) */
-    const uint4* qnodes;        /* the mesh nodes in 32 bytes, child boxes rounded outward to 16-bit planes (upload-time intermediate) */
-    const uint4* wnodes;        /* shadow walk: 4-wide nodes folded from qnodes, 64 bytes: 4 x (x,y,z plane pairs), 4 links */
+    const uint4* wnodes;        /* shadow walk: 4-wide nodes, 64 bytes: 4 x (x,y,z plane pairs of a child box rounded outward to 16 bits), 4 links */
     const DMesh* meshes;
     const float4* tnodes;
     const uint2* tleaves;

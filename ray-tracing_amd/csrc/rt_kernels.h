@@ -776,16 +776,18 @@ RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
  * So the reference reaches exactly the leaves whose OWN box passes its test, and the boxes above the
  * leaves may be replaced by anything that never loses such a leaf.
  *
- * k_shadow is bound by the vector L1's look-up rate (one 16-byte lane access per clock per CU when the
- * lanes sit at unrelated nodes), i.e. by the number of 16-byte pieces a ray
- * fetches. DScene::qnodes therefore holds the nodes in 32 bytes instead of 64: the child boxes rounded
- * OUTWARD to 16-bit planes in the mesh's frame (quantise_mesh in rtgpu.hip), x|y|z of a box as
- * lo | hi << 16. The test is conservative: one fma per plane, t = q*(qstep*inv) + ((qmin - o)*inv -/+
- * slack), slack = 2e-6 * max(|o|,|mesh|) * |1/d| of that axis -- more than the rounding differences
- * between this form on the padded planes and the reference's (plane - o)*inv on the true ones
- * (below 1e-6 * M * |inv| in total). v_max3/v_min3 drop NaN operands, which only loosens the test.
+ * The binary walk over the reference's 64-byte nodes saturates two things at once -- the vector L1 (one
+ * 16-byte lane access per clock per CU when the lanes sit at unrelated nodes) and VALU issue (DESIGN.md
+ * section 5) -- so the shadow tree cuts both: DScene::wnodes is the reference tree with every other level
+ * folded away (half the steps) and the child boxes rounded OUTWARD to 16-bit planes in the mesh's frame
+ * (a quarter of the bytes; quantise_mesh and WideFold in rtgpu.hip), x|y|z of a box as lo | hi << 16.
+ * The test is conservative: one fma per plane, t = q*(qstep*inv) + ((qmin - o)*inv -/+ slack),
+ * slack = 2e-6 * max(|o|,|mesh|) * |1/d| of that axis -- more than the rounding differences between
+ * this form on the padded planes and the reference's (plane - o)*inv on the true ones (below
+ * 1e-6 * M * |inv| in total). v_max3/v_min3 drop NaN operands, which only loosens the test.
  * A leaf is then entered only if the reference's own test (slab()) passes on the leaf's reference
- * box (slots 4-5 of the leaf's first triangle record), and its triangles are tested exactly as before: bit-identical occlusion. */
+ * box (slots 4-5 of the leaf's first triangle record), and its triangles are tested exactly as
+ * before: bit-identical occlusion. */
 #define TRI_NEW 0x80000000u
 RT_DEV void quant_setup(ShadowLane& s, const DMesh& m) {
     const Ray& r = s.r;

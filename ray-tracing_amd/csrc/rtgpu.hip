@@ -773,7 +773,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     const rt_bvh_node* dtn = nullptr;
     if ((rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
         (rc = upload(c, nodes, &dn)) || (rc = upload(c, meshes, &sc.meshes)) ||
-        (rc = upload(c, qnodes, &sc.qnodes)) || (rc = upload(c, wnodes, &sc.wnodes)) ||
+        (rc = upload(c, wnodes, &sc.wnodes)) ||
         (rc = upload(c, tnodes, &dtn)) || (rc = upload(c, tleaves, &sc.tleaves)) || (rc = upload(c, titems, &sc.titems)) ||
         (rc = upload(c, squares, &sc.squares)) || (rc = upload(c, spheres, &sc.spheres)) || (rc = upload(c, mats, &sc.mats)) ||
         (rc = upload(c, textures, &sc.textures)) ||

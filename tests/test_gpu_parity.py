@@ -300,6 +300,72 @@ def test_free_form_scene_and_edge_cases(rt, ctx):
     assert np.isnan(o).any(), "the degenerate triangle should poison some normals"
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_scenes(rt, ctx, seed):
+    """Random free-form scenes -- overlapping triangle clouds at several scales and tree depths (single-leaf meshes,
+    fat leaves, deep trees), slivers and degenerate triangles, spheres, walls, lights inside geometry: hits, shadow
+    queries and radiance against the oracle. This is what exercises the conservative shadow tree on geometry nobody
+    tuned it for."""
+    r = np.random.default_rng(seed)
+    hs, os_ = rt.HostScene(), O.Scene()
+    meshes = []
+    for k in range(int(r.integers(3, 7))):
+        nv = int(r.integers(3, 400))
+        scale = float(10.0 ** r.uniform(-1.5, 0.8))
+        centre = r.uniform(-3, 3, 3)
+        v = (centre + scale * r.normal(size=(nv, 3))).astype(np.float32)
+        nt = int(r.integers(1, 600))
+        t = r.integers(0, nv, (nt, 3)).astype(np.uint32)
+        if k == 0:                                    # slivers and a degenerate triangle
+            v[:3] = v[0] + np.array([[0, 0, 0], [1e-6, 0, 0], [0.5, 0.5e-6, 0]], np.float32) * scale
+            t[0] = [0, 1, 2]
+            t[1 % nt] = [0, 0, 1]
+        meshes.append((v, t))
+    spheres = [(r.uniform(-4, 4, 3).astype(np.float32), float(r.uniform(0.2, 1.5))) for _ in range(int(r.integers(0, 6)))]
+    wall = np.array([[-8, -4, -7], [8, -4, -7], [8, 6, -7], [-8, 6, -7]], np.float32)
+    floor = np.array([[-8, -4, 6], [8, -4, 6], [8, -4, -7], [-8, -4, -7]], np.float32)
+    mesh_depth, top_depth = int(r.integers(2, 20)), int(r.integers(1, 5))
+    for s, M in ((hs, rt), (os_, O)):
+        def mat(kind, k):
+            m = M.Material()
+            c = np.random.default_rng(1000 * seed + k).uniform(0.2, 1.0, 3)
+            m.kd[:] = c.tolist()
+            m.ks[:] = c.tolist()
+            m.shininess = 10.0
+            m.type = kind
+            m.ior = 1.3
+            m.transparency = 0.5 if kind == 1 else 0.0
+            m.reflectivity = 0.7 if kind == 2 else 0.0
+            return m
+        s.add_light([0.5, 4.0, 2.0], 0.4)
+        s.add_light(meshes[0][0][0].tolist(), 0.2)       # a light inside the first cloud
+        s.add_square(wall, mat(0, 0))
+        s.add_square(floor, mat(3, 1))
+        for k, (c, rad) in enumerate(spheres):
+            s.add_sphere(c, rad, mat(k % 3, 10 + k))
+        for k, (v, t) in enumerate(meshes):
+            s.add_mesh(v, t, mat(0 if k else 2, 20 + k))
+        s.build(top_depth, mesh_depth)
+    ctx.upload_scene(hs)
+    assert ctx.L.rt_uses_quantised_shadow_nodes(ctx.h) == 1
+    n = 6000
+    org = r.uniform(-5, 5, (n, 3)).astype(np.float32)
+    dirs = r.normal(size=(n, 3)).astype(np.float32)
+    dirs[:50, 0] = 0.0                                    # axis-parallel and zero-component directions
+    dirs[50:80, 1:] = 0.0
+    assert_hits_equal(ctx.intersect(org, dirs), os_.intersect(org, dirs), f"random scene {seed}")
+    lights = np.where(r.random((n, 1)) < 0.5, np.array([[0.5, 4.0, 2.0]], np.float32), meshes[0][0][0][None, :]).astype(np.float32)
+    pts = org.copy()
+    pts[: n // 2] = meshes[1][0][r.integers(0, len(meshes[1][0]), n // 2)] + r.normal(size=(n // 2, 3)).astype(np.float32) * 0.05
+    assert np.array_equal(ctx.occluded(pts, lights), os_.shadow(pts, lights))
+    oc = O.default_camera(1.0, zoom=0.0, z=-9.0)
+    co, cd = O.camera_rays(oc, O.make_params(56, 56, spp=1), 0, 0, 56, 56)
+    for shadow_mode in (0, 1):
+        g = ctx.trace(co, cd, rt.make_params(56, 56, spp=1, jitter=0, max_depth=6, shadow_mode=shadow_mode, seed=seed))
+        o = os_.trace(co, cd, O.make_params(56, 56, spp=1, max_depth=6, shadow_mode=shadow_mode, seed=seed))
+        radiance_check(g, o, f"random scene {seed} mode {shadow_mode}")
+
+
 def test_image_textures_and_normal_maps(rt, ctx):
     """Material::getColorAt / getNormalAt / applyTBN (Material.h:86-126, Scene.h:184-202) on every primitive kind and
     material type: textured diffuse / mirror / glass spheres (u,v from the ray direction), a floor with texture, normal
