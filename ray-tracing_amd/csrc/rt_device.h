@@ -69,7 +69,7 @@ struct DLight { float pos[3]; float radius; float color[3]; float pad; };
 struct DMesh {                 /* 48 B */
     int32_t root;              /* link of the tree's root */
     int32_t material;
-    float delta;               /* see prune_slack() */
+    float delta;               /* largest finite hit excursion of a child of this mesh (rtgpu.hip, HitBox); informational */
     float amax;                /* largest |coordinate| of the mesh's vertices */
     float qmin[3], qstep[3];   /* frame of the 16-bit box planes in DScene::wnodes: plane = qmin + q*qstep */
     int32_t wroot;             /* link of the 4-wide shadow tree's root */

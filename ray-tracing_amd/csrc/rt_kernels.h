@@ -57,21 +57,23 @@ RT_DEV int lds_index(int k, int stride) { return k * stride; }
  * no extra fetch; a leaf without triangles points at one shared all-zero record (normal 0 => d.n == 0
  * => Triangle::isParallelTo rejects it); LINK_NONE = no link. */
 #define LINK_NONE ((int)0x80000000)
+#define WIDE_UNPRUNED 0x40000000    /* on a link to a 4-wide shadow node: do not prune by distance in that node */
 RT_DEV uint32_t leaf_first(int link) { return (uint32_t)(-2 - link); }
 
-/* Result-preserving pruning. A triangle record is the mesh triangle scaled by 1.0001f about the
- * origin (Mesh.cpp:107-109) and accepted with a barycentric tolerance (Triangle.h:105), so its hit
- * point can lie up to ~1e-4*|coordinate| outside the (unscaled) box of its leaf. DMesh::delta
- * (8e-4 * largest |coordinate| of the mesh) bounds that with margin; moving a box face by delta moves
- * a slab entry time by at most delta*max|1/d|, hence every hit below a child has
- *     t >= (tEnter - delta*max|1/d|) * (1 - 1e-5).
- * A child whose bound exceeds the distance of interest cannot change the reference's answer (it
- * would lose the strict `<` of Mesh.cpp:114 or lie beyond the light), so it is skipped. The
- * reference's own slab test still decides which children are entered and in which order. */
-RT_DEV float prune_slack(const Ray& r, float delta) {
-    float m = fmaxf(fabsf(r.inv.x), fmaxf(fabsf(r.inv.y), fabsf(r.inv.z)));
-    return delta * m;    /* inf for axis-parallel rays: nothing is pruned */
+/* Result-preserving pruning. A child whose every possible hit lies beyond the distance of interest cannot
+ * change the reference's answer (the hit would lose the strict `<` of Mesh.cpp:114, or lie beyond the light),
+ * so it is skipped. "Every possible hit" needs care: a triangle record is the mesh triangle scaled by 1.0001f
+ * about the origin (Mesh.cpp:107-109) and accepted with a tolerance on the barycentric sum (Triangle.h:105), so
+ * its hits can lie outside the (unscaled) box of its leaf -- a little for ordinary triangles, without limit for
+ * degenerate ones. The upload bounds this per child (rtgpu.hip, tri_excursion / HitBox): words 14-15 of a
+ * 64-byte mesh node hold, for the left and the right child, how far accepted hits below it can leave its box
+ * (inf = no bound). Moving a box face by e moves a slab entry time by at most e*max|1/d|, hence every hit
+ * below a child has  t >= (tEnter - e*max|1/d|) * (1 - 1e-5).  The reference's own slab test still decides
+ * which children are entered and in which order. */
+RT_DEV float max_abs_inv(const Ray& r) {
+    return fmaxf(fabsf(r.inv.x), fmaxf(fabsf(r.inv.y), fabsf(r.inv.z)));    /* inf for axis-parallel rays: nothing is pruned */
 }
+/* NaN (0 * inf) compares false: not pruned */
 RT_DEV bool beyond(float tEnter, float slack, float bound) { return (tEnter - slack) * 0.99999f > bound; }
 
 /* BVH_Node::intersect + RayTraceMesh::intersect (AccelerationStruct.cpp:255-283, Mesh.cpp:97-123):
@@ -83,7 +85,7 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
     found = false;
     bestT = FLT_MAX;
     bestG = 0; bw0 = bw1 = bw2 = 0.f;
-    const float slack = prune_slack(r, m.delta);
+    const float mi = max_abs_inv(r);
     int sp = sp0;
     int link = m.root;
     for (;;) {
@@ -96,8 +98,8 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
             int left = __float_as_int(d.x), right = __float_as_int(d.y);
             float lim = fminf(bound, bestT);
             bool nearLeft = tL <= tR;                         /* AccelerationStruct.cpp:273 */
-            hL = hL && !beyond(tL, slack, lim);
-            hR = hR && !beyond(tR, slack, lim);
+            hL = hL && !beyond(tL, d.z * mi, lim);
+            hR = hR && !beyond(tR, d.w * mi, lim);
             if (hL && hR) {
                 if (nearLeft) { stk[lds_index(sp++, stride)] = right; link = left; }
                 else { stk[lds_index(sp++, stride)] = left; link = right; }
@@ -126,7 +128,7 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
  * that answer, so the nearer child goes first to find an occluder early.) With prune=false and
  * bound just below FLT_MAX this is "does RayTraceMesh::intersect return a hit at all". */
 RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound, bool prune, int* stk, int stride, int sp0) {
-    const float slack = prune ? prune_slack(r, m.delta) : INFINITY;
+    const float mi = prune ? max_abs_inv(r) : INFINITY;
     int sp = sp0;
     int link = m.root;
     for (;;) {
@@ -138,8 +140,8 @@ RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound
             bool hR = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
             int left = __float_as_int(d.x), right = __float_as_int(d.y);
             bool nearLeft = tL <= tR;
-            hL = hL && !beyond(tL, slack, bound);
-            hR = hR && !beyond(tR, slack, bound);
+            hL = hL && !beyond(tL, d.z * mi, bound);
+            hR = hR && !beyond(tR, d.w * mi, bound);
             if (hL && hR) {
                 if (nearLeft) { stk[lds_index(sp++, stride)] = right; link = left; }
                 else { stk[lds_index(sp++, stride)] = left; link = right; }
@@ -627,7 +629,9 @@ struct ShadowLane {
     Ray r;
     float bound;        /* lightDistance (mode 0) or just below FLT_MAX (mode 1) */
     float lightDistance;
-    float prune_t;      /* a child whose slab entry exceeds this cannot hold a hit at t <= bound (inf in mode 1) */
+    float prune_t;      /* a child whose hits all lie beyond this slab time cannot hold one at t <= bound (inf in mode 1;
+                         * quantised walk: already clamped to the reference's tMax = 100) */
+    float maxinv;       /* exact walk only: max |1/d|, turns a child's hit excursion into a slab-time slack */
     uint32_t key;       /* record*n_lights + light */
     int st, mode, visited, limit;
     int tlink, tsp;     /* top-level cursor and stack pointer */
@@ -677,9 +681,11 @@ RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane
                 if (sphere_test(s.r, q[0], t, n) && t <= s.bound) { shadow_on_hit(sc, s, cnt); if (s.st == ST_IDLE) return; }
             } else {
                 DMesh m = tt.meshes[ord - sc.n_squares - sc.n_spheres];
-                /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter > bound*1.00002 + slack is
+                /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter - slack > bound*1.00002 is
                  * still conservative and costs one compare per child */
-                s.prune_t = s.mode == 0 ? s.bound * 1.00002f + prune_slack(s.r, m.delta) : INFINITY;
+                s.prune_t = s.mode == 0 ? s.bound * 1.00002f : INFINITY;
+                if (QUANT) s.prune_t = fminf(100.0f, s.prune_t);     /* tMax of AABB::intersect */
+                else s.maxinv = max_abs_inv(s.r);
                 s.link = QUANT ? m.wroot : m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
                 if (QUANT) quant_setup(s, m);
                 s.st = ST_MESH;
@@ -736,8 +742,8 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
         bool hR = slab(s.r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
         int left = __float_as_int(d.x), right = __float_as_int(d.y);
         bool nearLeft = tL <= tR;
-        hL = hL && !(tL > s.prune_t);
-        hR = hR && !(tR > s.prune_t);
+        hL = hL && !(tL - d.z * s.maxinv > s.prune_t);      /* d.z, d.w: how far hits below the child leave its box */
+        hR = hR && !(tR - d.w * s.maxinv > s.prune_t);
         if (hL && hR) {
             stk[lds_index(s.msp++, stride)] = nearLeft ? right : left;
             link = nearLeft ? left : right;
@@ -837,9 +843,11 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
         link = s.msp <= w.lds_cap ? w.lds[--s.msp * RT_BLOCK] : wpop(w, s.msp);
     }
     if (link >= 0) {
-        const uint4* nd = sc.wnodes + 4 * (size_t)link;
+        /* the child boxes of this tree already hold every hit accepted below them (quantise_mesh), so a child entered
+         * beyond prune_t cannot matter; a node with a child that has no such bound is marked and only uses tMax */
+        const float lim = (link & WIDE_UNPRUNED) ? 100.0f : s.prune_t;
+        const uint4* nd = sc.wnodes + 4 * (size_t)(link & ~WIDE_UNPRUNED);
         uint4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
-        const float lim = fminf(100.0f, s.prune_t);                  /* tMax of AABB::intersect; beyond prune_t nothing can matter */
         bool h0, h1, h2, h3;
         float t0 = quant_entry(a.x, a.y, a.z, s, lim, h0);
         float t1 = quant_entry(a.w, b.x, b.y, s, lim, h1);
@@ -892,7 +900,7 @@ RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt
     if (s.tri_pos & TRI_NEW) {
         float4 b0 = q[4], b1 = q[5];                               /* the leaf's reference box rides in the same line */
         float tEnter;
-        reached = slab(s.r, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tEnter) && !(tEnter > s.prune_t);
+        reached = slab(s.r, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tEnter);
     }
     s.tri_pos = (!reached || __float_as_uint(q2.w) != 0u) ? TRI_NONE : pos + 1;
     if (s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link) | TRI_NEW; s.link = LINK_NONE; }

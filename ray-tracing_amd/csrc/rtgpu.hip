@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 #include <utility>
@@ -320,6 +321,55 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
 }
 
 
+/* ---- where can an accepted hit of a triangle record lie? Pruning by distance (rt_kernels.h, "result-preserving
+ * pruning") needs every accepted hit point to lie inside the box the prune test is made on. The reference accepts
+ * a point P of the triangle's (float) plane when the float sum of the three sub-areas over the stored area is in
+ * [0.9999, 1.00001] (Triangle.h:101-107) -- a NaN sum passes too -- so P can lie outside the triangle: by the
+ * tolerance, by the rounding of the sum (absolute, so it weighs more the smaller the area), and without limit for
+ * a triangle whose stored area is 0, NaN or lost in that rounding. With l the longest side, a the stored area,
+ * u = 2^-24 and rho the distance of P from the triangle:
+ *   sub-area sum S(P) >= A + g(P),  g >= h*rho/2 in the plane (h = least altitude),  S >= sqrt(A^2 + (z*l)^2) at
+ *   height z over it;  computed sum within E(rho) = 32*u*l*(l + rho) + 16*u*l^2 of S;  |a - A| <= 16*u*l^2;
+ *   accepted => g(P) <= G(rho) = 1.1e-5*a + 2*E(rho)
+ *   => rho <= F(rho) = 2*G(rho)/h + sqrt(2*a*G(rho) + G(rho)^2)/l,   F concave, so the least fixed point bounds rho.
+ * Returned: twice that fixed point (margin), or infinity if there is none. */
+double tri_excursion(const H3& c0, const H3& c1, const H3& c2, float area_f) {
+    const double u = 1.0 / 16777216.0;
+    auto side = [](const H3& a, const H3& b) {
+        double x = (double)a.x - b.x, y = (double)a.y - b.y, z = (double)a.z - b.z;
+        return std::sqrt(x * x + y * y + z * z);
+    };
+    const double l = std::max(side(c0, c1), std::max(side(c1, c2), side(c2, c0)));
+    const double a = (double)area_f;
+    if (!(a > 0.0) || !(a < 1e30) || !(l > 0.0) || !(l < 1e15)) return INFINITY;
+    const double A = a - 16.0 * u * l * l;
+    if (!(A > 0.0)) return INFINITY;
+    const double h = 2.0 * A / l;
+    const double G0 = 1.1e-5 * a + 96.0 * u * l * l, Gs = 64.0 * u * l;     /* G(rho) = G0 + Gs*rho */
+    if (!(2.0 * Gs / h + 2.0 * Gs / l < 0.25)) return INFINITY;             /* F must flatten well below the diagonal */
+    double rho = 0.0;
+    for (int it = 0; it < 200; it++) {
+        const double G = G0 + Gs * rho;
+        const double next = 2.0 * G / h + std::sqrt(2.0 * a * G + G * G) / l;
+        if (!(next < 1e30)) return INFINITY;
+        if (next <= rho * (1.0 + 1e-12)) break;
+        rho = next;
+    }
+    return 2.0 * rho;
+}
+
+/* what the accepted hits below one child of a mesh node stay inside: the union, over its triangle records, of the
+ * record's box grown by its excursion (+ a floor for the rounding of P = o + t*d itself); unbounded = some record
+ * below has no bound */
+struct HitBox {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool unbounded = false;
+    void add(const HitBox& o) {
+        for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], o.mn[k]); mx[k] = std::max(mx[k], o.mx[k]); }
+        unbounded = unbounded || o.unbounded;
+    }
+};
+
 /* ---- quantised shadow nodes (see rt_kernels.h). Every child box of a mesh tree is rounded OUTWARD to
  * 16-bit planes in the frame (qmin, qstep) of the mesh, one extra quantum of padding on each side, and
  * stored with the two links in 32 bytes: x,y,z of the left box as lo | hi << 16, then the right box,
@@ -328,13 +378,32 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
  * inverted box, or a child box that is not inside its parent's box (then "leaf box hit => every box
  * above it hit" does not hold and the exact walk is used instead). */
 bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<rt_bvh_node>& nodes, int32_t empty_link, DMesh& dm,
-                   std::vector<uint4>& qnodes, std::vector<float4>& lbox /* = the triangle records */) {
+                   std::vector<uint4>& qnodes, std::vector<float4>& lbox /* = the triangle records */,
+                   const std::vector<HitBox>& hbox, std::vector<uint8_t>& qunp) {
     double gmin[3] = {INFINITY, INFINITY, INFINITY}, gmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t v = 0; v < m.vert_count; v++)
         for (int k = 0; k < 3; k++) {
             double x = d->positions[3 * (m.vert_first + v) + k];
             if (!(std::fabs(x) < 1e30)) return false;
             gmin[k] = std::min(gmin[k], x); gmax[k] = std::max(gmax[k], x);
+        }
+    /* A child box is widened to hold the hits accepted below it (HitBox), so that pruning by distance on the widened
+     * box is exact; where no usable bound exists (further out than one mesh extent) the child keeps the reference
+     * box and is marked: the walk then does not prune in the node that holds it. */
+    const double reach = std::max(std::max(gmax[0] - gmin[0], gmax[1] - gmin[1]), std::max(gmax[2] - gmin[2], 1e-30));
+    const double vmin[3] = {gmin[0], gmin[1], gmin[2]}, vmax[3] = {gmax[0], gmax[1], gmax[2]};
+    auto usable = [&](const HitBox& hb) {
+        if (hb.unbounded) return false;
+        for (int k = 0; k < 3; k++)
+            if (hb.mn[k] <= hb.mx[k] && (!((double)hb.mn[k] >= vmin[k] - reach) || !((double)hb.mx[k] <= vmax[k] + reach))) return false;
+        return true;
+    };
+    for (int64_t i = 0; i < m.node_count; i++)
+        for (int s = 0; s < 2; s++) {
+            const HitBox& hb = hbox[2 * (size_t)(m.node_first + i) + s];
+            if (!usable(hb)) continue;
+            for (int k = 0; k < 3; k++)
+                if (hb.mn[k] <= hb.mx[k]) { gmin[k] = std::min(gmin[k], (double)hb.mn[k]); gmax[k] = std::max(gmax[k], (double)hb.mx[k]); }
         }
     float qmin[3], qstep[3];
     for (int k = 0; k < 3; k++) {
@@ -379,10 +448,15 @@ bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<r
         uint32_t w[6];
         for (int s = 0; s < 2; s++) {
             const bool empty = link[s] == empty_link;
+            const HitBox& hb = hbox[2 * (size_t)(m.node_first + i) + s];
+            const bool widen = usable(hb);
+            qunp[2 * (size_t)(m.node_first + i) + s] = !empty && !widen;
             for (int k = 0; k < 3; k++) {
                 if (empty) { w[3 * s + k] = 65535u; continue; }            /* lo = 65535, hi = 0 */
                 if (!(mn[s][k] <= mx[s][k]) || !(std::fabs(mn[s][k]) < 1e30f) || !(std::fabs(mx[s][k]) < 1e30f)) { ok = false; w[3 * s + k] = 0xFFFF0000u; continue; }
-                w[3 * s + k] = lo_q(mn[s][k], k) | (hi_q(mx[s][k], k) << 16);
+                float lo = mn[s][k], hi = mx[s][k];
+                if (widen && hb.mn[k] <= hb.mx[k]) { lo = std::min(lo, hb.mn[k]); hi = std::max(hi, hb.mx[k]); }
+                w[3 * s + k] = lo_q(lo, k) | (hi_q(hi, k) << 16);
             }
             if (empty) continue;
             if (link[s] >= 0) {                                             /* nesting: the child's two boxes lie inside this one */
@@ -413,11 +487,12 @@ struct WideFold {
     int32_t empty_link;
     const float* qstep;
     std::vector<uint4>& out;           /* 4 uint4 per wide node */
+    const std::vector<uint8_t>& unp;   /* per binary child: hits below it have no usable bound (quantise_mesh) */
     int depth = 0;
-    struct Cand { int32_t link; uint32_t w[3]; };
+    struct Cand { int32_t link; uint32_t w[3]; bool unp; };
     void children(int32_t node, Cand* c, int& n) const {
         const uint4 a = q[2 * (size_t)node], b = q[2 * (size_t)node + 1];
-        Cand l = {(int32_t)b.z, {a.x, a.y, a.z}}, r = {(int32_t)b.w, {a.w, b.x, b.y}};
+        Cand l = {(int32_t)b.z, {a.x, a.y, a.z}, unp[2 * (size_t)node] != 0}, r = {(int32_t)b.w, {a.w, b.x, b.y}, unp[2 * (size_t)node + 1] != 0};
         n = 0;
         if (l.link != empty_link) c[n++] = l;
         if (r.link != empty_link) c[n++] = r;
@@ -452,16 +527,18 @@ struct WideFold {
         for (int i = 0; i < 12; i++) words[i] = 65535u;
         for (int i = 12; i < 16; i++) words[i] = (uint32_t)LINK_NONE;
         int used = 0;
+        bool unpruned = false;             /* a slot of this node holds hits without a usable bound: its link says so */
         for (int i = 0; i < n; i++) {
             int32_t link = cand[i].link;
             if (link >= 0) { link = build(link, level + 1); if (link == LINK_NONE) continue; }
             for (int k = 0; k < 3; k++) words[3 * used + k] = cand[i].w[k];
             words[12 + used] = (uint32_t)link;
+            unpruned = unpruned || cand[i].unp;
             used++;
         }
         if (used == 0) { out.resize(4 * w); return LINK_NONE; }
         for (int r = 0; r < 4; r++) out[4 * w + r] = make_uint4(words[4 * r], words[4 * r + 1], words[4 * r + 2], words[4 * r + 3]);
-        return (int32_t)w;
+        return (int32_t)w | (unpruned ? (int32_t)WIDE_UNPRUNED : 0);
     }
 };
 
@@ -631,11 +708,17 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     /* shadow walk (rt_kernels.h, "quantised shadow nodes"): 32-byte copies of the nodes + the exact box of every leaf */
     std::vector<uint4> qnodes((size_t)d->n_mesh_nodes * 2, make_uint4(0u, 0u, 0u, 0u));
     std::vector<uint4> wnodes;                                              /* 4-wide shadow tree, all meshes */
+    std::vector<HitBox> hbox((size_t)d->n_mesh_nodes * 2);
+    std::vector<uint8_t> qunp((size_t)d->n_mesh_nodes * 2, 0);
+    std::vector<float> texc;
     bool quant_ok = true;
     int max_mesh_depth = 0, max_wide_depth = 0;
     for (int mi = 0; mi < d->n_meshes; mi++) {
         const rt_mesh& m = d->meshes[mi];
         max_mesh_depth = std::max(max_mesh_depth, m.depth);
+        float amax = 0.f;
+        for (int64_t v = 0; v < 3 * m.vert_count; v++) amax = std::max(amax, std::fabs(d->positions[3 * m.vert_first + v]));
+        texc.assign((size_t)m.tri_count, 0.f);
         for (int64_t j = 0; j < m.tri_count; j++) {
             uint32_t t = d->mesh_items[m.tri_first + j];
             const uint32_t* iv = d->tri_indices + 3 * (m.tri_first + t);
@@ -660,6 +743,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
             tri[RT_TRI_STRIDE * g + 2] = make_float4(c2.x, c2.y, c2.z, 0.f);
             tri[RT_TRI_STRIDE * g + 3] = make_float4(n.x, n.y, n.z, 0.f);
             ids[g] = make_uint4((uint32_t)(m.vert_first + iv[0]), (uint32_t)(m.vert_first + iv[1]), (uint32_t)(m.vert_first + iv[2]), t);
+            texc[(size_t)j] = (float)(tri_excursion(c0, c1, c2, area) + 1e-5 * (double)amax + 1e-6);
         }
         auto glob = [&](int32_t link) {
             if (link >= 0) return (int32_t)(link + m.node_first);
@@ -680,20 +764,70 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         }
         meshes[mi].root = glob(m.root);
         meshes[mi].material = m.material;
-        float amax = 0.f;
-        for (int64_t v = 0; v < 3 * m.vert_count; v++) amax = std::max(amax, std::fabs(d->positions[3 * m.vert_first + v]));
-        meshes[mi].delta = 8e-4f * amax + 1e-5f;
         meshes[mi].amax = amax;
         meshes[mi].pad = 0; meshes[mi].wroot = LINK_NONE;
-        quant_ok = quantise_mesh(d, m, nodes, (int32_t)(-2 - d->n_tris), meshes[mi], qnodes, tri) && quant_ok;
+        /* per child of every node: the box the accepted hits below it stay inside (see tri_excursion) */
+        const int32_t empty_link = (int32_t)(-2 - d->n_tris);
+        std::function<HitBox(int32_t)> below = [&](int32_t link) -> HitBox {
+            HitBox b;
+            if (link == empty_link) return b;
+            if (link < 0) {
+                size_t g = (size_t)(-2 - (int64_t)link);
+                for (bool last = false; !last; g++) {
+                    const float4 *q = &tri[RT_TRI_STRIDE * g];
+                    uint32_t flag;
+                    memcpy(&flag, &q[2].w, 4);
+                    last = flag != 0u;
+                    const float e = texc[g - (size_t)m.tri_first];
+                    if (!(e < 1e30f)) { b.unbounded = true; continue; }
+                    const float c[3][3] = {{q[0].x, q[0].y, q[0].z}, {q[1].x, q[1].y, q[1].z}, {q[2].x, q[2].y, q[2].z}};
+                    for (int k = 0; k < 3; k++) {
+                        b.mn[k] = std::min(b.mn[k], std::min(c[0][k], std::min(c[1][k], c[2][k])) - e);
+                        b.mx[k] = std::max(b.mx[k], std::max(c[0][k], std::max(c[1][k], c[2][k])) + e);
+                    }
+                }
+                return b;
+            }
+            const rt_bvh_node& n = nodes[(size_t)link];
+            HitBox l = below(n.left), r = below(n.right);
+            hbox[2 * (size_t)link] = l; hbox[2 * (size_t)link + 1] = r;
+            b.add(l); b.add(r);
+            return b;
+        };
+        float worst = 0.f;
+        if (meshes[mi].root >= 0) below(meshes[mi].root);
+        for (int64_t i = 0; i < m.node_count; i++) {       /* the exact walks prune in time: how far the hits leave the reference box */
+            rt_bvh_node& n = nodes[(size_t)(m.node_first + i)];
+            const float* mn[2] = {n.lmin, n.rmin};
+            const float* mx[2] = {n.lmax, n.rmax};
+            for (int s = 0; s < 2; s++) {
+                const HitBox& hb = hbox[2 * (size_t)(m.node_first + i) + s];
+                float e = 0.f;
+                for (int k = 0; k < 3; k++)
+                    if (hb.mn[k] <= hb.mx[k]) e = std::max(e, std::max(mn[s][k] - hb.mn[k], hb.mx[k] - mx[s][k]));
+                if (hb.unbounded || !(e < 1e30f)) e = INFINITY;
+                else worst = std::max(worst, e);
+                memcpy(&n.pad0[s], &e, 4);
+            }
+        }
+        meshes[mi].delta = worst;
+        quant_ok = quantise_mesh(d, m, nodes, empty_link, meshes[mi], qnodes, tri, hbox, qunp) && quant_ok;
         {
-            WideFold wf{qnodes, (int32_t)(-2 - d->n_tris), meshes[mi].qstep, wnodes};
+            WideFold wf{qnodes, empty_link, meshes[mi].qstep, wnodes, qunp};
             if (meshes[mi].root >= 0) meshes[mi].wroot = wf.build(meshes[mi].root, 0);
             else meshes[mi].wroot = meshes[mi].root == wf.empty_link ? LINK_NONE : meshes[mi].root;
             max_wide_depth = std::max(max_wide_depth, wf.depth);
         }
     }
     if (d->n_verts > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "too many vertices");
+    if (wnodes.size() / 4 >= (size_t)WIDE_UNPRUNED) return fail(c, RT_ERR_LIMIT, "too many mesh nodes");
+    if (c->debug) {
+        size_t unb = 0;
+        float worst = 0.f;
+        for (uint8_t f : qunp) unb += f;
+        for (const DMesh& m : meshes) worst = std::max(worst, m.delta);
+        fprintf(stderr, "[rtgpu] hit excursions: %zu of %zu mesh-node children without a usable bound, largest bounded one %g\n", unb, qunp.size(), (double)worst);
+    }
     std::vector<float> normals(d->normals, d->normals + 3 * d->n_verts);
 
     std::vector<float4> squares((size_t)d->n_squares * 4);

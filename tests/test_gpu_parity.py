@@ -366,6 +366,56 @@ def test_random_scenes(rt, ctx, seed):
         radiance_check(g, o, f"random scene {seed} mode {shadow_mode}")
 
 
+@pytest.mark.parametrize("mesh_depth", [2, 14])
+def test_sliver_clouds_and_distance_pruning(rt, ctx, mesh_depth):
+    """Needle triangles (height / length from 1e-3 down to 1e-8, any orientation, away from the origin): their stored
+    area is mostly rounding noise, so Triangle.h:101-107 accepts points well outside them -- or nowhere. The upload
+    bounds how far (tri_excursion in rtgpu.hip) and the pruning walks rely on that bound; rays aimed along the
+    needles' extended axes, lights just beyond the aim point (so that the distance bound is tight)."""
+    r = np.random.default_rng(77 + mesh_depth)
+    ns = 400
+    p = r.uniform(-3, 3, (ns, 3))
+    e = r.normal(size=(ns, 3)); e /= np.linalg.norm(e, axis=1, keepdims=True)
+    f = np.cross(e, r.normal(size=(ns, 3))); f /= np.linalg.norm(f, axis=1, keepdims=True)
+    L = 10.0 ** r.uniform(-1.0, 0.3, (ns, 1))
+    ratio = 10.0 ** r.uniform(-8, -3, (ns, 1))
+    v = np.empty((ns, 3, 3))
+    v[:, 0] = p
+    v[:, 1] = p + e * L
+    v[:, 2] = p + e * L * r.uniform(0.1, 0.9, (ns, 1)) + f * L * ratio
+    verts = v.reshape(-1, 3).astype(np.float32)
+    tris = np.arange(3 * ns, dtype=np.uint32).reshape(ns, 3)
+    hs, os_ = rt.HostScene(), O.Scene()
+    for s, M in ((hs, rt), (os_, O)):
+        m = M.Material()
+        m.kd[:] = [0.8, 0.6, 0.4]
+        s.add_light([0.0, 6.0, 0.0], 0.3)
+        s.add_mesh(verts, tris, m)
+        s.build(1, mesh_depth)
+    ctx.upload_scene(hs)
+    assert ctx.L.rt_uses_quantised_shadow_nodes(ctx.h) == 1
+    n = 20000
+    k = r.integers(0, ns, n)
+    tau = r.uniform(-2.0, 3.0, (n, 1))
+    aim = p[k] + e[k] * L[k] * tau + f[k] * L[k] * ratio[k] * r.uniform(-2, 2, (n, 1))
+    nrm = np.cross(e[k], f[k])
+    tilt = nrm + 0.3 * r.normal(size=(n, 3)) * r.integers(0, 2, (n, 1))
+    tilt /= np.linalg.norm(tilt, axis=1, keepdims=True)
+    dist = r.uniform(0.5, 6.0, (n, 1))
+    org = (aim + tilt * dist).astype(np.float32)
+    dirs = (-tilt).astype(np.float32)
+    assert_hits_equal(ctx.intersect(org, dirs), os_.intersect(org, dirs), "needles")
+    lights = (aim - tilt * 10.0 ** r.uniform(-4, -1, (n, 1))).astype(np.float32)      # just beyond the aim point
+    lights[::3] = (aim + tilt * 10.0 ** r.uniform(-4, -1, (n, 1)))[::3].astype(np.float32)   # or just before it
+    g, o = ctx.occluded(org, lights), os_.shadow(org, lights)
+    assert np.array_equal(g, o)
+    assert 0 < int(o.sum()) < n
+    for shadow_mode in (0, 1):                  # the persistent shadow kernel on the same rays
+        g = ctx.trace(org[:4096], dirs[:4096], rt.make_params(64, 64, spp=1, jitter=0, max_depth=2, shadow_mode=shadow_mode, seed=3))
+        o = os_.trace(org[:4096], dirs[:4096], O.make_params(64, 64, spp=1, max_depth=2, shadow_mode=shadow_mode, seed=3))
+        radiance_check(g, o, f"needles mode {shadow_mode}")
+
+
 def test_image_textures_and_normal_maps(rt, ctx):
     """Material::getColorAt / getNormalAt / applyTBN (Material.h:86-126, Scene.h:184-202) on every primitive kind and
     material type: textured diffuse / mirror / glass spheres (u,v from the ray direction), a floor with texture, normal
