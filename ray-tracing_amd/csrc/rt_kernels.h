@@ -58,6 +58,10 @@ RT_DEV int lds_index(int k, int stride) { return k * stride; }
  * => Triangle::isParallelTo rejects it); LINK_NONE = no link. */
 #define LINK_NONE ((int)0x80000000)
 #define WIDE_UNPRUNED 0x40000000    /* on a link to a 4-wide shadow node: do not prune by distance in that node */
+#define WIDE_SUB 0x20000000         /* ... the node belongs to the sub-tree of a fat leaf: the reference's tMax does not apply */
+#define WIDE_INDEX 0x1FFFFFFF
+#define TRI_SUB 0x40000000u         /* on a record index: a run inside a fat leaf (reached through the leaf's sub-tree) */
+#define TRI_LEAF_END 2u             /* record word 2.w: bit 0 = last of its run, bit 1 = last of its reference leaf */
 RT_DEV uint32_t leaf_first(int link) { return (uint32_t)(-2 - link); }
 
 /* Result-preserving pruning. A child whose every possible hit lies beyond the distance of interest cannot
@@ -76,16 +80,52 @@ RT_DEV float max_abs_inv(const Ray& r) {
 /* NaN (0 * inf) compares false: not pruned */
 RT_DEV bool beyond(float tEnter, float slack, float bound) { return (tEnter - slack) * 0.99999f > bound; }
 
+/* ---- a ray in the 16-bit plane frame of a mesh (see "quantised shadow nodes" further down): plane time =
+ * q*qa + qn (entry planes) / qf (exit planes) */
+struct QuantRay {
+    F3 qa, qn, qf;
+    uint32_t rot[3];    /* 16 where 1/d < 0: swaps the lo and hi halves of a packed plane pair */
+};
+RT_DEV void quant_setup(QuantRay& q, const Ray& r, const DMesh& m) {
+    float M = 1.01f * fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fmaxf(fabsf(r.o.z), m.amax));
+    float ix = fabsf(r.inv.x), iy = fabsf(r.inv.y), iz = fabsf(r.inv.z);
+    /* an infinite 1/d gives NaN or +-inf plane times in both forms; its slack is irrelevant, 0 keeps the constants clean */
+    float ex = 2e-6f * M * (ix < INFINITY ? ix : 0.f), ey = 2e-6f * M * (iy < INFINITY ? iy : 0.f), ez = 2e-6f * M * (iz < INFINITY ? iz : 0.f);
+    q.qa = f3(m.qstep[0] * r.inv.x, m.qstep[1] * r.inv.y, m.qstep[2] * r.inv.z);
+    float bx = (m.qmin[0] - r.o.x) * r.inv.x, by = (m.qmin[1] - r.o.y) * r.inv.y, bz = (m.qmin[2] - r.o.z) * r.inv.z;
+    q.qn = f3(bx - ex, by - ey, bz - ez);
+    q.qf = f3(bx + ex, by + ey, bz + ez);
+    q.rot[0] = r.inv.x < 0.0f ? 16u : 0u;      /* a negative 1/d swaps the roles of the two planes (AccelerationStruct.cpp:22) */
+    q.rot[1] = r.inv.y < 0.0f ? 16u : 0u;
+    q.rot[2] = r.inv.z < 0.0f ? 16u : 0u;
+}
+/* conservative entry time of one quantised box (three packed plane pairs); hit = the slab is not empty within [0, lim] */
+RT_DEV float quant_entry(uint32_t wx, uint32_t wy, uint32_t wz, const QuantRay& s, float lim, bool& hit) {
+    wx = __builtin_amdgcn_alignbit(wx, wx, s.rot[0]);
+    wy = __builtin_amdgcn_alignbit(wy, wy, s.rot[1]);
+    wz = __builtin_amdgcn_alignbit(wz, wz, s.rot[2]);
+    float a = __builtin_fmaf((float)(wx & 0xFFFFu), s.qa.x, s.qn.x), d = __builtin_fmaf((float)(wx >> 16), s.qa.x, s.qf.x);
+    float b = __builtin_fmaf((float)(wy & 0xFFFFu), s.qa.y, s.qn.y), e = __builtin_fmaf((float)(wy >> 16), s.qa.y, s.qf.y);
+    float c = __builtin_fmaf((float)(wz & 0xFFFFu), s.qa.z, s.qn.z), f = __builtin_fmaf((float)(wz >> 16), s.qa.z, s.qf.z);
+    float tMin = fmaxf(fmaxf(fmaxf(a, b), c), 0.0f);
+    float tMax = fminf(fminf(fminf(d, e), f), lim);
+    hit = tMin <= tMax;
+    return tMin;
+}
+
 /* BVH_Node::intersect + RayTraceMesh::intersect (AccelerationStruct.cpp:255-283, Mesh.cpp:97-123):
  * all leaves whose box chain is hit, near child first, first minimal t wins (strict <).
  * `bound` = the best t found so far in the leaf loop of intersectObjects: a mesh hit only counts
  * if it is strictly closer (AccelerationStruct.cpp:307). */
+template <bool SUB>     /* SUB: fat leaves carry sub-trees (DScene::has_sub and quant_ok) */
 RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float bound, int* stk, int stride, int sp0,
                          bool& found, float& bestT, uint32_t& bestG, float& bw0, float& bw1, float& bw2) {
     found = false;
     bestT = FLT_MAX;
     bestG = 0; bw0 = bw1 = bw2 = 0.f;
     const float mi = max_abs_inv(r);
+    QuantRay qr;
+    bool have_q = false;
     int sp = sp0;
     int link = m.root;
     for (;;) {
@@ -108,14 +148,60 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
             if (hL) { link = left; continue; }
             if (hR) { link = right; continue; }
         } else {
+            /* Mesh.cpp:111-119: strict <, so of equal t the first in the reference's order wins; the records of a fat
+             * leaf are regrouped (rtgpu.hip, LeafSplitter), word 3.w is their position in that order */
             uint32_t g = leaf_first(link);
-            for (bool last = false; !last; g++) {
-                const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)g;
-                float4 q2 = q[2];
-                last = __float_as_uint(q2.w) != 0u;
+            bool mine = false;
+            uint32_t bestP = 0;
+            auto candidate = [&](uint32_t gi, const float4* q, float4 q2, float4 q3) {
                 float t, w0, w1, w2;
-                if (tri_test(r, q[0], q[1], q2, q[3], t, w0, w1, w2) && t < bestT) {
-                    found = true; bestT = t; bestG = g; bw0 = w0; bw1 = w1; bw2 = w2;
+                if (tri_test(r, q[0], q[1], q2, q3, t, w0, w1, w2)) {
+                    const uint32_t p = __float_as_uint(q3.w);
+                    if (t < bestT || (mine && t == bestT && p < bestP)) {
+                        found = true; bestT = t; bestG = gi; bw0 = w0; bw1 = w1; bw2 = w2;
+                        mine = true; bestP = p;
+                    }
+                }
+            };
+            const float4 gate = SUB ? sc.tri[RT_TRI_STRIDE * (size_t)g + 6] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (__float_as_uint(gate.y) != 0u) {
+                /* a fat leaf: only the runs whose HitBox the ray reaches within the distance of interest can hold a
+                 * hit that counts (same boxes and test as the shadow walk, rtgpu.hip quantise_mesh) */
+                if (!have_q) { quant_setup(qr, r, m); have_q = true; }
+                const int spl = sp;
+                int sub = __float_as_int(gate.x);
+                for (;;) {
+                    if (sub >= 0) {
+                        const uint4* nd = sc.wnodes + 4 * (size_t)(sub & WIDE_INDEX);
+                        uint4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+                        const float lim = (sub & WIDE_UNPRUNED) ? INFINITY : fminf(bound, bestT) * 1.00002f;
+                        bool h0, h1, h2, h3;
+                        quant_entry(a.x, a.y, a.z, qr, lim, h0);
+                        quant_entry(a.w, b.x, b.y, qr, lim, h1);
+                        quant_entry(b.z, b.w, c.x, qr, lim, h2);
+                        quant_entry(c.y, c.z, c.w, qr, lim, h3);
+                        if (h0) stk[lds_index(sp++, stride)] = (int)d.x;
+                        if (h1) stk[lds_index(sp++, stride)] = (int)d.y;
+                        if (h2) stk[lds_index(sp++, stride)] = (int)d.z;
+                        if (h3) stk[lds_index(sp++, stride)] = (int)d.w;
+                    } else {
+                        uint32_t gi = leaf_first(sub) & ~TRI_SUB;
+                        for (bool last = false; !last; gi++) {
+                            const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)gi;
+                            float4 q2 = q[2];
+                            last = __float_as_uint(q2.w) != 0u;
+                            candidate(gi, q, q2, q[3]);
+                        }
+                    }
+                    if (sp == spl) break;
+                    sub = stk[lds_index(--sp, stride)];
+                }
+            } else {
+                for (bool last = false; !last; g++) {
+                    const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)g;
+                    float4 q2 = q[2];
+                    last = (__float_as_uint(q2.w) & TRI_LEAF_END) != 0u;
+                    candidate(g, q, q2, q[3]);
                 }
             }
         }
@@ -154,7 +240,7 @@ RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound
             for (bool last = false; !last; g++) {
                 const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)g;
                 float4 q2 = q[2];
-                last = __float_as_uint(q2.w) != 0u;
+                last = (__float_as_uint(q2.w) & TRI_LEAF_END) != 0u;
                 float t, w0, w1, w2;
                 if (tri_test(r, q[0], q[1], q2, q[3], t, w0, w1, w2) && t <= bound) return true;
             }
@@ -167,6 +253,7 @@ RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound
 
 /* BVH_Node::intersectObjects(ray) with stopAtFirst=false (AccelerationStruct.cpp:286-337):
  * every hit child is visited, left first; ties keep the earlier result. */
+template <bool SUB>
 RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
     HitD best;
     best.exists = 0; best.t = FLT_MAX; best.obj = -1; best.tri = 0; best.mat = 0;
@@ -209,7 +296,7 @@ RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
                 } else {
                     DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
                     bool found; float t; uint32_t g; float w0, w1, w2;
-                    mesh_closest(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
+                    mesh_closest<SUB>(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
                     if (found && t < best.t) {
                         best.exists = 1; best.t = t; best.obj = ord; kind = 2;
                         bestG = g; bw0 = w0; bw1 = w1; bw2 = w2; best.mat = m.material;
@@ -435,6 +522,7 @@ __global__ void __launch_bounds__(256) k_seed(const float* org, const float* dir
 
 /* Scene::rayTraceRecursive (Scene.h:174-280) for one path state: the recursion is unrolled into
  * child states carrying a throughput (radiance is linear in the child radiance, Scene.h:229,263-271). */
+template <bool SUB>
 __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
                                                       uint32_t child_cap, DiffuseRec* drec, unsigned long long* dcode, uint32_t* dtex,
                                                       uint32_t diffuse_cap, Counters* ctr, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
@@ -463,7 +551,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
         remaining = __float_as_int(p3.z); flags = __float_as_uint(p3.w);
 
         Ray r = make_ray(o, d);
-        HitD h = closest_hit(sc, r, stk, stride);
+        HitD h = closest_hit<SUB>(sc, r, stk, stride);
         if ((flags & 1u) && prim) {
             prim[2 * (size_t)slot] = h.exists ? (uint32_t)h.obj : 0xFFFFFFFFu;
             prim[2 * (size_t)slot + 1] = h.exists ? (uint32_t)h.tri : 0xFFFFFFFFu;
@@ -632,6 +720,7 @@ struct ShadowLane {
     float prune_t;      /* a child whose hits all lie beyond this slab time cannot hold one at t <= bound (inf in mode 1;
                          * quantised walk: already clamped to the reference's tMax = 100) */
     float maxinv;       /* exact walk only: max |1/d|, turns a child's hit excursion into a slab-time slack */
+    float prune_raw;    /* quantised walk with leaf sub-trees: prune_t without the tMax clamp */
     uint32_t key;       /* record*n_lights + light */
     int st, mode, visited, limit;
     int tlink, tsp;     /* top-level cursor and stack pointer */
@@ -640,9 +729,7 @@ struct ShadowLane {
     int link, msp;      /* mesh cursor and stack pointer */
     uint32_t tri_pos;   /* next triangle record of the leaf being tested, TRI_NONE if none; quantised walk: bit 31
                          * (TRI_NEW) = the leaf's own box is still to be tested */
-    /* quantised walk only, set when a mesh is entered: plane time = q*qa + qn (entry planes) / qf (exit planes) */
-    F3 qa, qn, qf;
-    uint32_t rot[3];    /* 16 where 1/d < 0: swaps the lo and hi halves of a packed plane pair */
+    QuantRay q;         /* quantised walk only, set when a mesh is entered */
 };
 
 RT_DEV void shadow_restart(const DScene& sc, ShadowLane& s, int mode, int limit) {
@@ -665,7 +752,6 @@ RT_DEV void shadow_on_hit(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
 struct TopTables { const float4* tnodes; const uint2* tleaves; const uint32_t* titems; const float4* squares; const float4* spheres; const DMesh* meshes; };
 #define RT_TOP_LDS_MAX 2048
 /* top-level state machine: runs until the ray ends or enters a mesh tree */
-RT_DEV void quant_setup(ShadowLane& s, const DMesh& m);
 template <bool QUANT>
 RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane& s, int* stk, int stride, uint32_t* cnt) {
     for (;;) {
@@ -684,10 +770,11 @@ RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane
                 /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter - slack > bound*1.00002 is
                  * still conservative and costs one compare per child */
                 s.prune_t = s.mode == 0 ? s.bound * 1.00002f : INFINITY;
+                s.prune_raw = s.prune_t;
                 if (QUANT) s.prune_t = fminf(100.0f, s.prune_t);     /* tMax of AABB::intersect */
                 else s.maxinv = max_abs_inv(s.r);
                 s.link = QUANT ? m.wroot : m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
-                if (QUANT) quant_setup(s, m);
+                if (QUANT) quant_setup(s.q, s.r, m);
                 s.st = ST_MESH;
                 return;
             }
@@ -763,7 +850,7 @@ RT_DEV void shadow_node_step(const DScene& sc, ShadowLane& s, int* stk, int stri
 RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)s.tri_pos;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    s.tri_pos = __float_as_uint(q2.w) != 0u ? TRI_NONE : s.tri_pos + 1;
+    s.tri_pos = (__float_as_uint(q2.w) & TRI_LEAF_END) != 0u ? TRI_NONE : s.tri_pos + 1;
     if (s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link); s.link = LINK_NONE; }   /* the blocked leaf is next */
     s.st = can_walk(s, sc.top_cap) ? ST_MESH : ST_BLOCKED;
     float t, w0, w1, w2;
@@ -795,33 +882,6 @@ RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
  * box (slots 4-5 of the leaf's first triangle record), and its triangles are tested exactly as
  * before: bit-identical occlusion. */
 #define TRI_NEW 0x80000000u
-RT_DEV void quant_setup(ShadowLane& s, const DMesh& m) {
-    const Ray& r = s.r;
-    float M = 1.01f * fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fmaxf(fabsf(r.o.z), m.amax));
-    float ix = fabsf(r.inv.x), iy = fabsf(r.inv.y), iz = fabsf(r.inv.z);
-    /* an infinite 1/d gives NaN or +-inf plane times in both forms; its slack is irrelevant, 0 keeps the constants clean */
-    float ex = 2e-6f * M * (ix < INFINITY ? ix : 0.f), ey = 2e-6f * M * (iy < INFINITY ? iy : 0.f), ez = 2e-6f * M * (iz < INFINITY ? iz : 0.f);
-    s.qa = f3(m.qstep[0] * r.inv.x, m.qstep[1] * r.inv.y, m.qstep[2] * r.inv.z);
-    float bx = (m.qmin[0] - r.o.x) * r.inv.x, by = (m.qmin[1] - r.o.y) * r.inv.y, bz = (m.qmin[2] - r.o.z) * r.inv.z;
-    s.qn = f3(bx - ex, by - ey, bz - ez);
-    s.qf = f3(bx + ex, by + ey, bz + ez);
-    s.rot[0] = r.inv.x < 0.0f ? 16u : 0u;      /* a negative 1/d swaps the roles of the two planes (AccelerationStruct.cpp:22) */
-    s.rot[1] = r.inv.y < 0.0f ? 16u : 0u;
-    s.rot[2] = r.inv.z < 0.0f ? 16u : 0u;
-}
-/* conservative entry time of one quantised box (three packed plane pairs); hit = the slab is not empty within [0, lim] */
-RT_DEV float quant_entry(uint32_t wx, uint32_t wy, uint32_t wz, const ShadowLane& s, float lim, bool& hit) {
-    wx = __builtin_amdgcn_alignbit(wx, wx, s.rot[0]);
-    wy = __builtin_amdgcn_alignbit(wy, wy, s.rot[1]);
-    wz = __builtin_amdgcn_alignbit(wz, wz, s.rot[2]);
-    float a = __builtin_fmaf((float)(wx & 0xFFFFu), s.qa.x, s.qn.x), d = __builtin_fmaf((float)(wx >> 16), s.qa.x, s.qf.x);
-    float b = __builtin_fmaf((float)(wy & 0xFFFFu), s.qa.y, s.qn.y), e = __builtin_fmaf((float)(wy >> 16), s.qa.y, s.qf.y);
-    float c = __builtin_fmaf((float)(wz & 0xFFFFu), s.qa.z, s.qn.z), f = __builtin_fmaf((float)(wz >> 16), s.qa.z, s.qf.z);
-    float tMin = fmaxf(fmaxf(fmaxf(a, b), c), 0.0f);
-    float tMax = fminf(fminf(fminf(d, e), f), lim);
-    hit = tMin <= tMax;
-    return tMin;
-}
 /* The 4-wide walk can have three links pending per level. Only the first lds_cap entries of a lane's stack
  * live in LDS (what keeps 16 waves on a CU); deeper ones -- rare -- go to a per-lane slice of global memory,
  * entry k of lane l of block b at ovf[(b*ovf_cap + k)*64 + l]. */
@@ -836,23 +896,29 @@ RT_DEV int wpop(const WideStack& w, int& sp) {
 }
 /* one 4-wide node (64 bytes: twelve packed plane pairs, four links): the nearest hit child next, the others pushed.
  * Stack traffic stays in LDS unless this step could cross lds_cap (then, and only then, the spilling push/pop run). */
+template <bool SUB>
 RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& w) {
     int link = s.link;
-    if (link == LINK_NONE) {
+    if (link == LINK_NONE) {                                         /* the one place where the walk pops */
         if (s.msp == sc.top_cap) { s.st = ST_TOP; return; }        /* mesh done without a hit: next object of the leaf */
-        link = s.msp <= w.lds_cap ? w.lds[--s.msp * RT_BLOCK] : wpop(w, s.msp);
+        --s.msp;
+        if (s.msp < w.lds_cap) link = w.lds[s.msp * RT_BLOCK];
+        else { asm volatile("" ::: "memory"); link = w.ovf[(s.msp - w.lds_cap) * RT_BLOCK]; }   /* (kept a branch: a select of the two addresses becomes a flat load) */
     }
     if (link >= 0) {
         /* the child boxes of this tree already hold every hit accepted below them (quantise_mesh), so a child entered
          * beyond prune_t cannot matter; a node with a child that has no such bound is marked and only uses tMax */
-        const float lim = (link & WIDE_UNPRUNED) ? 100.0f : s.prune_t;
-        const uint4* nd = sc.wnodes + 4 * (size_t)(link & ~WIDE_UNPRUNED);
+        float lim = (link & WIDE_UNPRUNED) ? 100.0f : s.prune_t;
+        /* below a fat leaf's own box the reference tests triangles, not boxes: no tMax there (a triangle of a leaf
+         * entered before t = 100 may be hit beyond it) */
+        if (SUB && (link & WIDE_SUB)) lim = (link & WIDE_UNPRUNED) ? INFINITY : s.prune_raw;
+        const uint4* nd = sc.wnodes + 4 * (size_t)(link & WIDE_INDEX);
         uint4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
         bool h0, h1, h2, h3;
-        float t0 = quant_entry(a.x, a.y, a.z, s, lim, h0);
-        float t1 = quant_entry(a.w, b.x, b.y, s, lim, h1);
-        float t2 = quant_entry(b.z, b.w, c.x, s, lim, h2);
-        float t3 = quant_entry(c.y, c.z, c.w, s, lim, h3);
+        float t0 = quant_entry(a.x, a.y, a.z, s.q, lim, h0);
+        float t1 = quant_entry(a.w, b.x, b.y, s.q, lim, h1);
+        float t2 = quant_entry(b.z, b.w, c.x, s.q, lim, h2);
+        float t3 = quant_entry(c.y, c.z, c.w, s.q, lim, h3);
         const int l0 = (int)d.x, l1 = (int)d.y, l2 = (int)d.z, l3 = (int)d.w;
         /* nearest hit child first (an occluder is usually found early that way); the order of the rest is free */
 #if RT_CHILD_ORDER == 0
@@ -881,8 +947,7 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
                 if (p3) wpush(w, s.msp, l3);
             }
             link = la;
-        } else if (s.msp > sc.top_cap) link = s.msp <= w.lds_cap ? w.lds[--s.msp * RT_BLOCK] : wpop(w, s.msp);
-        else link = LINK_NONE;
+        } else link = LINK_NONE;                                      /* nothing hit: the next step pops */
     }
     if (link < 0 && link != LINK_NONE && s.tri_pos == TRI_NONE) {
         s.tri_pos = leaf_first(link) | TRI_NEW;
@@ -891,16 +956,23 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
     s.link = link;
     if (!can_walk(s, sc.top_cap)) s.st = ST_BLOCKED;
 }
-/* one triangle of a leaf of the quantised walk; the first one brings the reference's test of the leaf's own box along */
-RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
-    const uint32_t pos = s.tri_pos & ~TRI_NEW;
+/* one triangle of a leaf of the quantised walk; the first one brings the reference's test of the leaf's own box along.
+ * SUB: a fat leaf that passes hands over to its sub-tree (pushed; words 24-25 of the record), whose runs are then
+ * reached like leaves but without a box of their own to test. */
+template <bool SUB>
+RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt, const WideStack& w) {
+    const uint32_t pos = s.tri_pos & (SUB ? ~(TRI_NEW | TRI_SUB) : ~TRI_NEW);
     const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)pos;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     bool reached = true;
-    if (s.tri_pos & TRI_NEW) {
+    if ((s.tri_pos & TRI_NEW) && !(SUB && (s.tri_pos & TRI_SUB))) {
         float4 b0 = q[4], b1 = q[5];                               /* the leaf's reference box rides in the same line */
         float tEnter;
         reached = slab(s.r, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tEnter);
+        if (SUB && reached) {
+            float4 gate = q[6];
+            if (__float_as_uint(gate.y) != 0u) { wpush(w, s.msp, __float_as_int(gate.x)); reached = false; }
+        }
     }
     s.tri_pos = (!reached || __float_as_uint(q2.w) != 0u) ? TRI_NONE : pos + 1;
     if (s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link) | TRI_NEW; s.link = LINK_NONE; }
@@ -949,11 +1021,12 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
 
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
-template <bool QUANT, bool COUNT>      /* COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
+template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
                                                         uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds,
                                                         int* ovf, int lds_cap, int ovf_cap) {
     constexpr bool count_steps = COUNT;
+    constexpr bool QUANT = MODE != 0, SUB = MODE == 2;
     extern __shared__ __align__(16) int s_stack[];
     unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0, c_wn = 0, c_wt = 0, c_wtop = 0, c_ltop = 0;
     int* stk = s_stack + threadIdx.x;
@@ -1041,7 +1114,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             unsigned long long mw = __builtin_amdgcn_ballot_w64(walking), mt = __builtin_amdgcn_ballot_w64(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wn++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
-            if (walking) { if (QUANT) shadow_quant_step(sc, s, wst); else shadow_node_step(sc, s, stk, stride); }
+            if (walking) { if (QUANT) shadow_quant_step<SUB>(sc, s, wst); else shadow_node_step(sc, s, stk, stride); }
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_nodeph += k_t1 - k_t0; k_t0 = k_t1; }
         /* triangle phase: worth a round once enough lanes have a leaf pending, or when the walkers are the minority */
@@ -1058,7 +1131,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             if (np == 0) break;
             if (k > 0 && np < RT_TRI_MORE && __builtin_amdgcn_ballot_w64(s.st == ST_MESH) != 0ull) break;   /* a thin follow-up round only if nobody could walk instead */
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wt++; if (pending) c_tri++; }
-            if (pending) { if (QUANT) shadow_quant_tri_step(sc, s, cnt); else shadow_tri_step(sc, s, cnt); }
+            if (pending) { if (QUANT) shadow_quant_tri_step<SUB>(sc, s, cnt, wst); else shadow_tri_step(sc, s, cnt); }
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_triph += k_t1 - k_t0; }
     }
@@ -1125,12 +1198,13 @@ __global__ void __launch_bounds__(256) k_resolve(const long long* acc, const uin
 
 /* Scene::computeIntersection on explicit rays (rt_intersect). */
 struct HitOut { int32_t exists, obj, tri; float t; float pos[3]; float nrm[3]; float u, v; };
+template <bool SUB>
 __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene sc, const float* org, const float* dir, uint32_t n, HitOut* out) {
     extern __shared__ __align__(16) int s_stack[];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r = make_ray(f3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), f3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
-    HitD h = closest_hit(sc, r, s_stack + threadIdx.x, blockDim.x);
+    HitD h = closest_hit<SUB>(sc, r, s_stack + threadIdx.x, blockDim.x);
     HitOut o;
     o.exists = h.exists; o.obj = h.exists ? h.obj : -1; o.tri = h.exists ? h.tri : 0; o.t = h.exists ? h.t : FLT_MAX;
     o.pos[0] = h.pos.x; o.pos[1] = h.pos.y; o.pos[2] = h.pos.z;

@@ -157,6 +157,8 @@ bool m4_inverse(const double* m, double* out) {
 }
 
 size_t lds_bytes(const rt_ctx* c, int block) { return (size_t)c->sc.stack_cap * block * sizeof(int); }
+/* the closest-hit walks also keep the links of a fat leaf's sub-tree on the lane's stack */
+size_t lds_bytes_closest(const rt_ctx* c, int block) { return (size_t)c->sc.cstack_cap * block * sizeof(int); }
 
 EventPair* next_event(rt_ctx* c, int kind) {
     if (c->ev_used == c->ev_pool.size()) {
@@ -231,9 +233,12 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         EventPair* e1 = next_event(c, 0);
         if (!e1) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
         HIP_TRY(c, hipEventRecord(e1->a, c->stream));
-        hipLaunchKernelGGL(k_closest, dim3((nb + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, c->stream, c->sc, stack + base, nb,
-                           static_cast<PathState*>(c->child.p), 2 * B, static_cast<DiffuseRec*>(c->drec.p),
-                           static_cast<unsigned long long*>(c->dcode.p), static_cast<uint32_t*>(c->dtex.p), B, d_ctr, acc, nonfinite, prim);
+        auto launch_closest = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((nb + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds_bytes_closest(c, RT_BLOCK), c->stream, c->sc, stack + base, nb,
+                               static_cast<PathState*>(c->child.p), 2 * B, static_cast<DiffuseRec*>(c->drec.p),
+                               static_cast<unsigned long long*>(c->dcode.p), static_cast<uint32_t*>(c->dtex.p), B, d_ctr, acc, nonfinite, prim);
+        };
+        if (c->sc.has_sub && c->sc.quant_ok) launch_closest(k_closest<true>); else launch_closest(k_closest<false>);
         HIP_TRY(c, hipEventRecord(e1->b, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -277,8 +282,9 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                                        static_cast<const float4*>(c->srays.p), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds,
                                        static_cast<int*>(c->ovf.p), lds_cap, ovf_cap);
                 };
-                if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<true, true>); else launch(k_shadow<true, false>); }
-                else { if (c->count_steps) launch(k_shadow<false, true>); else launch(k_shadow<false, false>); }
+                if (c->sc.quant_ok && c->sc.has_sub) { if (c->count_steps) launch(k_shadow<2, true>); else launch(k_shadow<2, false>); }
+                else if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<1, true>); else launch(k_shadow<1, false>); }
+                else { if (c->count_steps) launch(k_shadow<0, true>); else launch(k_shadow<0, false>); }
                 HIP_TRY(c, hipEventRecord(e2->b, c->stream));
             }
         }
@@ -370,6 +376,102 @@ struct HitBox {
     }
 };
 
+/* ---- sub-trees inside fat leaves. The reference visits every triangle of a leaf whose box chain the ray passes
+ * (AccelerationStruct.cpp:255-283, Mesh.cpp:97-123); with the spatial-median builder stopping at depth 12 a leaf
+ * of the gorilla holds 299 of them. Which of them can be HIT is bounded by their HitBoxes, so inside such a leaf
+ * the library may skip what the ray cannot reach: the records of a fat leaf are regrouped into short runs under a
+ * binary SAH tree of HitBoxes (folded into the 4-wide shadow tree below the leaf, behind the reference's test of
+ * the leaf's own box). The walks that need the reference's order inside a leaf (closest hit: the first of equal
+ * t wins, Mesh.cpp:114) get each record's original position along. */
+#ifndef RT_LEAF_SPLIT
+#define RT_LEAF_SPLIT 6          /* leaves with more triangles than this get a sub-tree */
+#endif
+#ifndef RT_SPLIT_SHARE
+#define RT_SPLIT_SHARE 0.02
+#endif
+#ifndef RT_SUB_RUN
+#define RT_SUB_RUN 2             /* triangles per run (sub-tree leaf) */
+#endif
+struct SubNode { HitBox box[2]; int32_t link[2]; };     /* link >= 0: index into the sub-node array; < 0: a run, -2 - (first record | TRI_SUB) */
+struct LeafSplitter {
+    const std::vector<HitBox>& tb;          /* per record of the leaf (local index): its HitBox */
+    const std::vector<H3>& cen;             /* per record: centre of the triangle's own box */
+    std::vector<int>& order;                /* new position -> old local index */
+    std::vector<SubNode>& subs;
+    size_t first_record;                    /* global record index of the leaf's first triangle */
+    std::vector<int>& run_last;             /* new positions that end a run */
+    int depth = 0;
+    static double half_area(const HitBox& b) {
+        if (b.unbounded) return 1e30;
+        if (!(b.mn[0] <= b.mx[0])) return 0.0;
+        double x = (double)b.mx[0] - b.mn[0], y = (double)b.mx[1] - b.mn[1], z = (double)b.mx[2] - b.mn[2];
+        return x * y + y * z + z * x;
+    }
+    int32_t build(int lo, int hi, HitBox& out, int level) {
+        out = HitBox();
+        for (int i = lo; i < hi; i++) out.add(tb[(size_t)order[(size_t)i]]);
+        if (hi - lo <= RT_SUB_RUN) {
+            run_last.push_back(hi - 1);
+            return (int32_t)(-2 - (int64_t)((first_record + (size_t)lo) | (size_t)TRI_SUB));
+        }
+        depth = std::max(depth, level + 1);
+        /* binned SAH over the three axes; a degenerate distribution falls back to halving the range */
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = lo; i < hi; i++) {
+            const H3& c = cen[(size_t)order[(size_t)i]];
+            const float v[3] = {c.x, c.y, c.z};
+            for (int k = 0; k < 3; k++) { cmn[k] = std::min(cmn[k], v[k]); cmx[k] = std::max(cmx[k], v[k]); }
+        }
+        constexpr int NB = 16;
+        double best = INFINITY;
+        int best_axis = -1, best_bin = 0;
+        for (int k = 0; k < 3; k++) {
+            const float ext = cmx[k] - cmn[k];
+            if (!(ext > 0.f) || !(ext < 1e30f)) continue;
+            HitBox bins[NB];
+            int cnt[NB] = {0};
+            for (int i = lo; i < hi; i++) {
+                const size_t o = (size_t)order[(size_t)i];
+                const float v = k == 0 ? cen[o].x : k == 1 ? cen[o].y : cen[o].z;
+                int b = (int)((v - cmn[k]) / ext * NB);
+                b = std::min(std::max(b, 0), NB - 1);
+                bins[b].add(tb[o]); cnt[b]++;
+            }
+            HitBox rb[NB];
+            int rc[NB];
+            HitBox acc; int n = 0;
+            for (int b = NB - 1; b >= 0; b--) { acc.add(bins[b]); n += cnt[b]; rb[b] = acc; rc[b] = n; }
+            acc = HitBox(); n = 0;
+            for (int b = 0; b + 1 < NB; b++) {
+                acc.add(bins[b]); n += cnt[b];
+                if (n == 0 || rc[b + 1] == 0) continue;
+                const double cost = half_area(acc) * n + half_area(rb[b + 1]) * rc[b + 1];
+                if (cost < best) { best = cost; best_axis = k; best_bin = b; }
+            }
+        }
+        int mid;
+        if (best_axis < 0) mid = (lo + hi) / 2;
+        else {
+            const int k = best_axis;
+            const float ext = cmx[k] - cmn[k];
+            auto in_left = [&](int o) {
+                const float v = k == 0 ? cen[(size_t)o].x : k == 1 ? cen[(size_t)o].y : cen[(size_t)o].z;
+                int b = (int)((v - cmn[k]) / ext * NB);
+                b = std::min(std::max(b, 0), NB - 1);
+                return b <= best_bin;
+            };
+            mid = (int)(std::stable_partition(order.begin() + lo, order.begin() + hi, in_left) - order.begin());
+            if (mid == lo || mid == hi) mid = (lo + hi) / 2;
+        }
+        const size_t me = subs.size();
+        subs.emplace_back();
+        HitBox bl, br;
+        const int32_t l = build(lo, mid, bl, level + 1), r = build(mid, hi, br, level + 1);
+        subs[me].box[0] = bl; subs[me].box[1] = br; subs[me].link[0] = l; subs[me].link[1] = r;
+        return (int32_t)me;
+    }
+};
+
 /* ---- quantised shadow nodes (see rt_kernels.h). Every child box of a mesh tree is rounded OUTWARD to
  * 16-bit planes in the frame (qmin, qstep) of the mesh, one extra quantum of padding on each side, and
  * stored with the two links in 32 bytes: x,y,z of the left box as lo | hi << 16, then the right box,
@@ -379,7 +481,8 @@ struct HitBox {
  * above it hit" does not hold and the exact walk is used instead). */
 bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<rt_bvh_node>& nodes, int32_t empty_link, DMesh& dm,
                    std::vector<uint4>& qnodes, std::vector<float4>& lbox /* = the triangle records */,
-                   const std::vector<HitBox>& hbox, std::vector<uint8_t>& qunp) {
+                   const std::vector<HitBox>& hbox, std::vector<uint8_t>& qunp,
+                   const std::vector<SubNode>& subs, size_t sub_lo, size_t sub_base /* index of subs[0] in qnodes */) {
     double gmin[3] = {INFINITY, INFINITY, INFINITY}, gmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t v = 0; v < m.vert_count; v++)
         for (int k = 0; k < 3; k++) {
@@ -398,13 +501,15 @@ bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<r
             if (hb.mn[k] <= hb.mx[k] && (!((double)hb.mn[k] >= vmin[k] - reach) || !((double)hb.mx[k] <= vmax[k] + reach))) return false;
         return true;
     };
+    auto cover = [&](const HitBox& hb) {
+        if (!usable(hb)) return;
+        for (int k = 0; k < 3; k++)
+            if (hb.mn[k] <= hb.mx[k]) { gmin[k] = std::min(gmin[k], (double)hb.mn[k]); gmax[k] = std::max(gmax[k], (double)hb.mx[k]); }
+    };
     for (int64_t i = 0; i < m.node_count; i++)
-        for (int s = 0; s < 2; s++) {
-            const HitBox& hb = hbox[2 * (size_t)(m.node_first + i) + s];
-            if (!usable(hb)) continue;
-            for (int k = 0; k < 3; k++)
-                if (hb.mn[k] <= hb.mx[k]) { gmin[k] = std::min(gmin[k], (double)hb.mn[k]); gmax[k] = std::max(gmax[k], (double)hb.mx[k]); }
-        }
+        for (int s = 0; s < 2; s++) cover(hbox[2 * (size_t)(m.node_first + i) + s]);
+    for (size_t i = sub_lo; i < subs.size(); i++)
+        for (int s = 0; s < 2; s++) cover(subs[i].box[s]);
     float qmin[3], qstep[3];
     for (int k = 0; k < 3; k++) {
         double step = std::max((gmax[k] - gmin[k]) / 65000.0, 1e-30);
@@ -434,10 +539,24 @@ bool quantise_mesh(const rt_scene_desc* d, const rt_mesh& m, const std::vector<r
     };
     const float ninf[3] = {-INFINITY, -INFINITY, -INFINITY}, pinf[3] = {INFINITY, INFINITY, INFINITY};
     const int32_t groot = nodes.empty() || m.root < 0 ? -1 : (int32_t)(m.root + m.node_first);
+    /* the sub-trees of fat leaves: HitBoxes only (what lies below is reached through the leaf's own box) */
+    for (size_t i = sub_lo; i < subs.size(); i++) {
+        uint32_t w[6];
+        int32_t link[2];
+        for (int s = 0; s < 2; s++) {
+            const HitBox& hb = subs[i].box[s];
+            const bool widen = usable(hb) && hb.mn[0] <= hb.mx[0];
+            qunp[2 * (sub_base + i) + s] = !widen;
+            for (int k = 0; k < 3; k++) w[3 * s + k] = widen ? (lo_q(hb.mn[k], k) | (hi_q(hb.mx[k], k) << 16)) : 0xFFFF0000u;
+            link[s] = subs[i].link[s] >= 0 ? (int32_t)(sub_base + (size_t)subs[i].link[s]) : subs[i].link[s];
+        }
+        qnodes[2 * (sub_base + i)] = make_uint4(w[0], w[1], w[2], w[3]);
+        qnodes[2 * (sub_base + i) + 1] = make_uint4(w[4], w[5], (uint32_t)link[0], (uint32_t)link[1]);
+    }
     if (m.root < 0) {      /* the whole mesh is one leaf: its triangles are always reached (the root has no box) */
         const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + (-1 - m.root)];
         if (lf.count) leaf_box((int32_t)(-2 - (int64_t)(lf.first + m.tri_first)), ninf, pinf);
-        return true;
+        return ok;
     }
     (void)groot;
     for (int64_t i = 0; i < m.node_count; i++) {
@@ -488,6 +607,7 @@ struct WideFold {
     const float* qstep;
     std::vector<uint4>& out;           /* 4 uint4 per wide node */
     const std::vector<uint8_t>& unp;   /* per binary child: hits below it have no usable bound (quantise_mesh) */
+    int32_t link_flags = 0;            /* WIDE_SUB while folding the sub-tree of a fat leaf */
     int depth = 0;
     struct Cand { int32_t link; uint32_t w[3]; bool unp; };
     void children(int32_t node, Cand* c, int& n) const {
@@ -538,7 +658,7 @@ struct WideFold {
         }
         if (used == 0) { out.resize(4 * w); return LINK_NONE; }
         for (int r = 0; r < 4; r++) out[4 * w + r] = make_uint4(words[4 * r], words[4 * r + 1], words[4 * r + 2], words[4 * r + 3]);
-        return (int32_t)w | (unpruned ? (int32_t)WIDE_UNPRUNED : 0);
+        return (int32_t)w | (unpruned ? (int32_t)WIDE_UNPRUNED : 0) | link_flags;
     }
 };
 
@@ -618,7 +738,7 @@ int check_desc(rt_ctx* c, const rt_scene_desc* d) {
                 if (d->tri_indices[3 * (m.tri_first + i) + k] >= (uint64_t)m.vert_count) return fail(c, RT_ERR_ARG, "mesh %d: vertex index out of range", mi);
         }
     }
-    if (d->n_tris > 0x7FFFFFF0ll || d->n_mesh_nodes > 0x7FFFFFF0ll || d->n_mesh_leaves > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "scene too large for 32-bit links");
+    if (d->n_tris > 0x1FFFFFF0ll || d->n_mesh_nodes > 0x7FFFFFF0ll || d->n_mesh_leaves > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "scene too large for 32-bit links");
     return RT_OK;
 }
 
@@ -698,10 +818,14 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
 
     /* triangles in leaf order with the per-test quantities of Triangle.h precomputed */
     std::vector<float4> tri(((size_t)d->n_tris + 1) * RT_TRI_STRIDE, make_float4(0.f, 0.f, 0.f, 0.f));   /* +1: the record empty leaves point at */
-    {
-        uint32_t one = 1u;
-        memcpy(&tri[RT_TRI_STRIDE * (size_t)d->n_tris + 2].w, &one, 4);
-    }
+    /* word 2.w of a record: bit 0 = last record of its run, bit 1 = last record of its (reference) leaf */
+    auto flag_record = [&](size_t g, uint32_t bits) {
+        uint32_t f;
+        memcpy(&f, &tri[RT_TRI_STRIDE * g + 2].w, 4);
+        f |= bits;
+        memcpy(&tri[RT_TRI_STRIDE * g + 2].w, &f, 4);
+    };
+    flag_record((size_t)d->n_tris, 3u);
     std::vector<uint4> ids((size_t)d->n_tris);
     std::vector<rt_bvh_node> nodes(d->mesh_nodes, d->mesh_nodes + d->n_mesh_nodes);
     std::vector<DMesh> meshes((size_t)d->n_meshes);
@@ -711,8 +835,18 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     std::vector<HitBox> hbox((size_t)d->n_mesh_nodes * 2);
     std::vector<uint8_t> qunp((size_t)d->n_mesh_nodes * 2, 0);
     std::vector<float> texc;
+    std::vector<SubNode> subs;                                              /* sub-trees of fat leaves, all meshes */
+    /* the sub-tree variants of the kernels cost a few per cent where no leaf is fat, so a handful of fat leaves
+     * (C5 has five among millions) is not worth them: at least RT_SPLIT_SHARE of the triangles must sit in fat leaves */
+    bool split_leaves = false;
+    {
+        int64_t fat = 0;
+        for (int64_t i = 0; i < d->n_mesh_leaves; i++) if (d->mesh_leaves[i].count > (uint32_t)RT_LEAF_SPLIT) fat += d->mesh_leaves[i].count;
+        split_leaves = !getenv("RT_NO_LEAF_SPLIT") && (double)fat >= RT_SPLIT_SHARE * (double)d->n_tris && fat > 0;
+        if (getenv("RT_FORCE_LEAF_SPLIT")) split_leaves = fat > 0;       /* test knob */
+    }
     bool quant_ok = true;
-    int max_mesh_depth = 0, max_wide_depth = 0;
+    int max_mesh_depth = 0, max_wide_depth = 0, max_sub_depth = 0, max_wide_sub_depth = 0;
     for (int mi = 0; mi < d->n_meshes; mi++) {
         const rt_mesh& m = d->meshes[mi];
         max_mesh_depth = std::max(max_mesh_depth, m.depth);
@@ -755,12 +889,61 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
             n.left = glob(n.left);
             n.right = glob(n.right);
         }
-        for (int64_t i = 0; i < m.leaf_count; i++) {           /* flag the last triangle record of every leaf */
+        const size_t sub_lo = subs.size();
+        std::vector<std::pair<size_t, int32_t>> gates;          /* fat leaves: first record, root of the sub-tree (index into subs) */
+        for (int64_t i = 0; i < m.leaf_count; i++) {
             const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + i];
-            if (lf.count) {
-                uint32_t one = 1u;
-                memcpy(&tri[RT_TRI_STRIDE * (size_t)(m.tri_first + lf.first + lf.count - 1) + 2].w, &one, 4);
+            if (!lf.count) continue;
+            const size_t g0 = (size_t)(m.tri_first + lf.first), n = lf.count;
+            flag_record(g0 + n - 1, 3u);
+            auto set_position = [&](size_t g, uint32_t pos) { memcpy(&tri[RT_TRI_STRIDE * g + 3].w, &pos, 4); };
+            if (!split_leaves || n <= (size_t)RT_LEAF_SPLIT) {
+                for (size_t p = 0; p < n; p++) set_position(g0 + p, (uint32_t)p);
+                continue;
             }
+            /* a fat leaf: runs of records under a sub-tree; every record keeps its position in the reference's order */
+            std::vector<HitBox> tb(n);
+            std::vector<H3> cen(n);
+            std::vector<int> order(n);
+            for (size_t p = 0; p < n; p++) {
+                const float4* q = &tri[RT_TRI_STRIDE * (g0 + p)];
+                const float e = texc[g0 + p - (size_t)m.tri_first];
+                const float cc[3][3] = {{q[0].x, q[0].y, q[0].z}, {q[1].x, q[1].y, q[1].z}, {q[2].x, q[2].y, q[2].z}};
+                float lo[3], hi[3];
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = std::min(cc[0][k], std::min(cc[1][k], cc[2][k]));
+                    hi[k] = std::max(cc[0][k], std::max(cc[1][k], cc[2][k]));
+                }
+                cen[p] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+                if (!(e < 1e30f)) tb[p].unbounded = true;
+                else for (int k = 0; k < 3; k++) { tb[p].mn[k] = lo[k] - e; tb[p].mx[k] = hi[k] + e; }
+                order[p] = (int)p;
+            }
+            std::vector<int> run_last;
+            LeafSplitter ls{tb, cen, order, subs, g0, run_last};
+            HitBox all;
+            const int32_t root = ls.build(0, (int)n, all, 0);
+            max_sub_depth = std::max(max_sub_depth, ls.depth);
+            gates.emplace_back(g0, root);
+            std::vector<float4> rec(n * RT_TRI_STRIDE);
+            std::vector<uint4> rid(n);
+            std::vector<float> rex(n);
+            for (size_t p = 0; p < n; p++) {
+                const size_t o = g0 + (size_t)order[p];
+                std::copy(tri.begin() + RT_TRI_STRIDE * o, tri.begin() + RT_TRI_STRIDE * (o + 1), rec.begin() + RT_TRI_STRIDE * p);
+                rid[p] = ids[o];
+                rex[p] = texc[o - (size_t)m.tri_first];
+            }
+            std::copy(rec.begin(), rec.end(), tri.begin() + RT_TRI_STRIDE * g0);
+            std::copy(rid.begin(), rid.end(), ids.begin() + g0);
+            std::copy(rex.begin(), rex.end(), texc.begin() + (g0 - (size_t)m.tri_first));
+            for (size_t p = 0; p < n; p++) {
+                set_position(g0 + p, (uint32_t)order[p]);
+                uint32_t zero = 0u;
+                memcpy(&tri[RT_TRI_STRIDE * (g0 + p) + 2].w, &zero, 4);
+            }
+            for (int p : run_last) flag_record(g0 + (size_t)p, 1u);
+            flag_record(g0 + n - 1, 3u);
         }
         meshes[mi].root = glob(m.root);
         meshes[mi].material = m.material;
@@ -777,7 +960,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
                     const float4 *q = &tri[RT_TRI_STRIDE * g];
                     uint32_t flag;
                     memcpy(&flag, &q[2].w, 4);
-                    last = flag != 0u;
+                    last = (flag & 2u) != 0u;
                     const float e = texc[g - (size_t)m.tri_first];
                     if (!(e < 1e30f)) { b.unbounded = true; continue; }
                     const float c[3][3] = {{q[0].x, q[0].y, q[0].z}, {q[1].x, q[1].y, q[1].z}, {q[2].x, q[2].y, q[2].z}};
@@ -811,21 +994,36 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
             }
         }
         meshes[mi].delta = worst;
-        quant_ok = quantise_mesh(d, m, nodes, empty_link, meshes[mi], qnodes, tri, hbox, qunp) && quant_ok;
+        const size_t sub_base = (size_t)d->n_mesh_nodes;
+        qnodes.resize(2 * (sub_base + subs.size()), make_uint4(0u, 0u, 0u, 0u));
+        qunp.resize(2 * (sub_base + subs.size()), 0);
+        quant_ok = quantise_mesh(d, m, nodes, empty_link, meshes[mi], qnodes, tri, hbox, qunp, subs, sub_lo, sub_base) && quant_ok;
         {
             WideFold wf{qnodes, empty_link, meshes[mi].qstep, wnodes, qunp};
             if (meshes[mi].root >= 0) meshes[mi].wroot = wf.build(meshes[mi].root, 0);
             else meshes[mi].wroot = meshes[mi].root == wf.empty_link ? LINK_NONE : meshes[mi].root;
             max_wide_depth = std::max(max_wide_depth, wf.depth);
+            /* the sub-trees hang behind their leaves: words 24-25 of the leaf's first record = (link, 1) */
+            wf.link_flags = (int32_t)WIDE_SUB;
+            for (const auto& gate : gates) {
+                wf.depth = 0;
+                const int32_t sl = wf.build((int32_t)(sub_base + (size_t)gate.second), 0);
+                max_wide_sub_depth = std::max(max_wide_sub_depth, wf.depth);
+                const uint32_t mark = 1u;
+                float4 w6 = make_float4(0.f, 0.f, 0.f, 0.f);
+                memcpy(&w6.x, &sl, 4); memcpy(&w6.y, &mark, 4);
+                tri[RT_TRI_STRIDE * gate.first + 6] = w6;
+            }
         }
     }
     if (d->n_verts > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "too many vertices");
-    if (wnodes.size() / 4 >= (size_t)WIDE_UNPRUNED) return fail(c, RT_ERR_LIMIT, "too many mesh nodes");
+    if (wnodes.size() / 4 >= (size_t)WIDE_SUB) return fail(c, RT_ERR_LIMIT, "too many mesh nodes");
     if (c->debug) {
         size_t unb = 0;
         float worst = 0.f;
         for (uint8_t f : qunp) unb += f;
         for (const DMesh& m : meshes) worst = std::max(worst, m.delta);
+        fprintf(stderr, "[rtgpu] fat leaves (more than %d triangles): %zu sub-tree nodes, wide depth %d below the leaves\n", RT_LEAF_SPLIT, subs.size(), max_wide_sub_depth);
         fprintf(stderr, "[rtgpu] hit excursions: %zu of %zu mesh-node children without a usable bound, largest bounded one %g\n", unb, qunp.size(), (double)worst);
     }
     std::vector<float> normals(d->normals, d->normals + 3 * d->n_verts);
@@ -948,7 +1146,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     }
     sc.top_cap = d->top_depth + 2;
     sc.stack_cap = sc.top_cap + max_mesh_depth + 2;
-    sc.wstack_cap = sc.top_cap + 3 * max_wide_depth + 2;
+    sc.cstack_cap = sc.stack_cap + (subs.empty() ? 0 : 3 * max_wide_sub_depth + 5);
+    sc.wstack_cap = sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 3;
+    sc.has_sub = subs.empty() ? 0 : 1;
     sc.quant_ok = (quant_ok && !getenv("RT_SHADOW_EXACT_NODES")) ? 1 : 0;
     if (c->debug) fprintf(stderr, "[rtgpu] scene: %lld mesh nodes, depth %d, quantised shadow nodes %s\n", (long long)d->n_mesh_nodes, max_mesh_depth,
                           sc.quant_ok ? "on" : "off");
@@ -1129,8 +1329,11 @@ int rt_intersect(rt_ctx* c, const float* org, const float* dir, int64_t n, rt_hi
         release(a); release(b); release(o);
         return rc;
     }
-    hipLaunchKernelGGL(k_intersect, dim3(((uint32_t)n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds_bytes(c, RT_BLOCK), c->stream, c->sc,
-                       static_cast<const float*>(a.p), static_cast<const float*>(b.p), (uint32_t)n, static_cast<HitOut*>(o.p));
+    auto launch_intersect = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(((uint32_t)n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds_bytes_closest(c, RT_BLOCK), c->stream, c->sc,
+                           static_cast<const float*>(a.p), static_cast<const float*>(b.p), (uint32_t)n, static_cast<HitOut*>(o.p));
+    };
+    if (c->sc.has_sub && c->sc.quant_ok) launch_intersect(k_intersect<true>); else launch_intersect(k_intersect<false>);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, o.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost);
     release(a); release(b); release(o);

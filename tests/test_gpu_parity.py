@@ -200,10 +200,10 @@ def test_small_batches_same_frame(rt, ctx, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["final", "mesh_gorilla"])
+@pytest.mark.parametrize("name", ["final", "mesh_gorilla", "soup:20000"])
 def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
-    """The quantised 32-byte shadow nodes (default) and the exact 64-byte nodes give identical frames;
-    a tree whose boxes are not nested switches the quantised nodes off by itself."""
+    """The quantised 4-wide shadow tree (default) and the exact 64-byte nodes give identical frames, with and without
+    sub-trees inside fat leaves; a tree whose boxes are not nested switches the quantised nodes off by itself."""
     hs, os_ = scene_pair(rt, ctx, name)
     cam = rt.default_camera(1.0, zoom=25.0) if name == "final" else rt.default_camera(1.0)
     p = rt.make_params(64, 64, spp=2, max_depth=6, seed=3)
@@ -228,6 +228,17 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
         c4.close()
     monkeypatch.delenv("RT_WIDE_LDS_CAP")
     assert np.array_equal(bits(spilled), bits(quant)) and sst.rays_shadow == qst.rays_shadow
+    # fat leaves walked triangle by triangle (no sub-trees), and sub-trees in every leaf of more than 6 triangles
+    for knob in ("RT_NO_LEAF_SPLIT", "RT_FORCE_LEAF_SPLIT"):
+        monkeypatch.setenv(knob, "1")
+        c5 = rt.Context(0)
+        try:
+            c5.upload_scene(hs)
+            other, oprim, ost = c5.render(cam, p)
+        finally:
+            c5.close()
+        monkeypatch.delenv(knob)
+        assert np.array_equal(bits(other), bits(quant)) and np.array_equal(oprim, qprim) and ost.rays_shadow == qst.rays_shadow, knob
     # shrink one child box of a mesh root below its own children's boxes: not nested any more
     dp = hs.desc
     d = dp.contents
