@@ -774,7 +774,18 @@ RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane
                 if (QUANT) s.prune_t = fminf(100.0f, s.prune_t);     /* tMax of AABB::intersect */
                 else s.maxinv = max_abs_inv(s.r);
                 s.link = QUANT ? m.wroot : m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
-                if (QUANT) quant_setup(s.q, s.r, m);
+                if (QUANT) {
+                    quant_setup(s.q, s.r, m);
+                    /* The reference tests no box for the mesh as a whole (Mesh.cpp:97-123 starts at the root's
+                     * children), but every box of the shadow tree lies inside the mesh's plane frame: a ray that
+                     * misses the whole frame (or reaches it beyond the distance of interest) cannot reach a leaf,
+                     * and stays at the top level -- scenes with dozens of meshes are mostly such visits. */
+                    if (m.wroot >= 0) {
+                        bool hit;
+                        quant_entry(0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, s.q, (m.wroot & WIDE_UNPRUNED) ? 100.0f : s.prune_t, hit);
+                        if (!hit) continue;
+                    }
+                }
                 s.st = ST_MESH;
                 return;
             }
