@@ -1032,10 +1032,10 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
 
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
-template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
+template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves and batched top-level rounds. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
                                                         uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds,
-                                                        int* ovf, int lds_cap, int ovf_cap) {
+                                                        int* ovf, int lds_cap, int ovf_cap, int top_min) {
     constexpr bool count_steps = COUNT;
     constexpr bool QUANT = MODE != 0, SUB = MODE == 2;
     extern __shared__ __align__(16) int s_stack[];
@@ -1114,7 +1114,15 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             continue;
         }
         if (count_steps) { if (s.st == ST_TOP) c_ltop++; k_t1 = __builtin_readcyclecounter(); k_refill += k_t1 - k_t0; k_t0 = k_t1; }
-        if (s.st == ST_TOP) shadow_advance_top<QUANT>(sc, tt, s, stk, stride, cnt);
+        /* top-level work runs lane by lane to its next mesh (or the end of the ray), so in a scene with many objects a
+         * round for one or two lanes stalls the wave: there the host asks to wait until top_min lanes want one,
+         * unless nothing else can move */
+        bool top_round = true;
+        if (SUB && top_min > 1) {       /* (MODE 2 only: the host picks that kernel for scenes with many top-level objects too) */
+            const int ntop = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_TOP));
+            top_round = ntop >= top_min || __builtin_amdgcn_ballot_w64(s.st >= ST_MESH) == 0ull;
+        }
+        if (top_round && s.st == ST_TOP) shadow_advance_top<QUANT>(sc, tt, s, stk, stride, cnt);
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_top += k_t1 - k_t0; k_t0 = k_t1; }
         /* node phase */
 #pragma unroll 1

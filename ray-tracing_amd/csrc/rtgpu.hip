@@ -269,7 +269,9 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 uint32_t* cnt0 = static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L;
                 /* small top-level tables (a few objects) are copied into LDS behind the stacks: a new ray walks them
                  * through four dependent loads while the other lanes of its wave wait */
-                const int top_lds = (c->sc.top_blob_bytes <= RT_TOP_LDS_MAX && !getenv("RT_TOP_GLOBAL")) ? 1 : 0;
+                /* (room: 16 blocks per CU share 160 KB of LDS, so stacks + tables may take 10 KB per block) */
+                const size_t top_room = std::max<size_t>(RT_TOP_LDS_MAX, lds < 10240 ? 10240 - lds : 0);
+                const int top_lds = ((size_t)c->sc.top_blob_bytes <= top_room && !getenv("RT_TOP_GLOBAL")) ? 1 : 0;
                 /* stack entries of a lane kept in LDS (the first stack_cap = what the binary walks need; the 4-wide shadow walk
                  * can need three per level and spills the rest -- rare -- to a global slice) */
                 int lds_cap = c->sc.stack_cap;
@@ -277,12 +279,14 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                     if (c->sc.quant_ok && atoi(e) > 0) lds_cap = std::max(c->sc.top_cap + 1, std::min(lds_cap, atoi(e)));
                 const int ovf_cap = c->sc.quant_ok ? std::max(0, c->sc.wstack_cap - lds_cap) : 0;
                 if ((rc = ensure(c, c->ovf, std::max<size_t>(256, (size_t)blocks * ovf_cap * RT_BLOCK * sizeof(int))))) return rc;
+                int top_min = c->sc.n_top_items >= 24 ? 32 : 1;       /* see k_shadow; measured on the default scene: 1, 8, 16, 32, 48, 60 -> 2365, 2205, 2065, 1828, 1839, 2111 ms */
+                if (const char* e = getenv("RT_TOP_MIN")) top_min = std::max(1, atoi(e));
                 auto launch = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, c->sc,
                                        static_cast<const float4*>(c->srays.p), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds,
-                                       static_cast<int*>(c->ovf.p), lds_cap, ovf_cap);
+                                       static_cast<int*>(c->ovf.p), lds_cap, ovf_cap, top_min);
                 };
-                if (c->sc.quant_ok && c->sc.has_sub) { if (c->count_steps) launch(k_shadow<2, true>); else launch(k_shadow<2, false>); }
+                if (c->sc.quant_ok && (c->sc.has_sub || top_min > 1)) { if (c->count_steps) launch(k_shadow<2, true>); else launch(k_shadow<2, false>); }
                 else if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<1, true>); else launch(k_shadow<1, false>); }
                 else { if (c->count_steps) launch(k_shadow<0, true>); else launch(k_shadow<0, false>); }
                 HIP_TRY(c, hipEventRecord(e2->b, c->stream));
@@ -1137,6 +1141,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         sc.top_blob = reinterpret_cast<const float4*>(db);
         sc.top_blob_bytes = (int32_t)blob.size();
     }
+    sc.n_top_items = d->n_top_items;
     sc.n_lights = d->n_lights; sc.n_squares = d->n_squares; sc.n_spheres = d->n_spheres; sc.n_meshes = d->n_meshes;
     sc.top_root = (d->n_squares + d->n_spheres + d->n_meshes) > 0 ? d->top_root : -1;
     if ((d->n_squares + d->n_spheres + d->n_meshes) == 0) {
