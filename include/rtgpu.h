@@ -182,6 +182,12 @@ int rt_get_stats(rt_ctx*, rt_stats* stats);
  * quantised copies of the mesh nodes (all mesh boxes finite and nested, as bounding boxes of triangle
  * sets are), 0 if they walk the reference's nodes directly, negative on error. Results are identical. */
 int rt_uses_quantised_shadow_nodes(const rt_ctx*);
+/* Diagnostic, no counterpart in the reference, needs no GPU: the bound the distance pruning of rt_upload_scene relies
+ * on. For the mesh triangle (v0, v1, v2) of a mesh whose largest |coordinate| is amax: how far from the triangle
+ * record (the triangle scaled by 1.0001f, Mesh.cpp:107-109) a hit accepted by Triangle::getIntersection
+ * (Triangle.h:101-107, barycentric sum in [0.9999, 1.00001]) can lie; infinity if the acceptance test gives no
+ * bound (degenerate triangles). Tests hold it against the oracle's accepted hits. */
+double rt_hit_excursion(const float v0[3], const float v1[3], const float v2[3], float amax);
 
 /* Fine-grained seams, host arrays in and out:
  * Scene::computeIntersection (Scene.h:84-88) on n rays (origin, direction as given to Ray()). */

@@ -762,6 +762,13 @@ uint32_t rt_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code, u
 
 const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+double rt_hit_excursion(const float v0[3], const float v1[3], const float v2[3], float amax) {
+    const float s = 1.0001f;                                   /* the record of rt_upload_scene */
+    H3 c0 = {s * v0[0], s * v0[1], s * v0[2]}, c1 = {s * v1[0], s * v1[1], s * v1[2]}, c2 = {s * v2[0], s * v2[1], s * v2[2]};
+    const float area = hlen(hcross(hsub(c1, c0), hsub(c2, c0))) / 2.f;
+    return (double)(float)(tri_excursion(c0, c1, c2, area) + 1e-5 * (double)amax + 1e-6);
+}
+
 int rt_uses_quantised_shadow_nodes(const rt_ctx* c) {
     if (!c) return RT_ERR_ARG;
     if (!c->has_scene) return RT_ERR_STATE;
