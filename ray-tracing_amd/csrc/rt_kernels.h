@@ -713,19 +713,27 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
 #define RT_TRI_STEPS 4        /* triangle-phase steps per round */
 #endif
 
+#define TS_MODE 1u
+#define TS_OPEN 2u
+#define TS_SP_ONE 4u
+#define TS_SP(ts) (((ts) >> 2) & 63u)
+#define TS_VISITED_ONE 0x100u
+#define TS_VISITED(ts) (((ts) >> 8) & 0xFFFu)
+#define TS_LIMIT(ts) ((ts) >> 20)
 struct ShadowLane {
     Ray r;
     float bound;        /* lightDistance (mode 0) or just below FLT_MAX (mode 1) */
-    float lightDistance;
     float prune_t;      /* a child whose hits all lie beyond this slab time cannot hold one at t <= bound (inf in mode 1;
                          * quantised walk: already clamped to the reference's tMax = 100) */
     float maxinv;       /* exact walk only: max |1/d|, turns a child's hit excursion into a slab-time slack */
     float prune_raw;    /* quantised walk with leaf sub-trees: prune_t without the tMax clamp */
     uint32_t key;       /* record*n_lights + light */
-    int st, mode, visited, limit;
-    int tlink, tsp;     /* top-level cursor and stack pointer */
+    int st;
+    /* the small top-level state shares one register (k_shadow has none to spare): bit 0 mode, bit 1 a leaf is open,
+     * bits 2-7 top-level stack pointer, bits 8-19 leaves visited, bits 20-31 limit (mode 1: leaves to look at) */
+    uint32_t ts;
+    int tlink;          /* top-level cursor */
     uint32_t top_pos, top_end;
-    int leaf_open;
     int link, msp;      /* mesh cursor and stack pointer */
     uint32_t tri_pos;   /* next triangle record of the leaf being tested, TRI_NONE if none; quantised walk: bit 31
                          * (TRI_NEW) = the leaf's own box is still to be tested */
@@ -733,9 +741,9 @@ struct ShadowLane {
 };
 
 RT_DEV void shadow_restart(const DScene& sc, ShadowLane& s, int mode, int limit) {
-    s.mode = mode; s.limit = limit; s.visited = 0;
-    s.bound = mode == 0 ? s.lightDistance : 3.4028233e38f;
-    s.tlink = sc.top_root; s.tsp = 0; s.top_pos = s.top_end = 0; s.leaf_open = 0;
+    s.ts = (uint32_t)mode | ((uint32_t)limit << 20);
+    if (mode == 1) s.bound = 3.4028233e38f;             /* (mode 0: the refill has put lightDistance there) */
+    s.tlink = sc.top_root; s.top_pos = s.top_end = 0;
     s.st = ST_TOP;
 }
 RT_DEV void shadow_finish(ShadowLane& s, bool occ, uint32_t* cnt) {
@@ -744,9 +752,10 @@ RT_DEV void shadow_finish(ShadowLane& s, bool occ, uint32_t* cnt) {
 }
 /* an object of the current leaf is hit at t <= bound */
 RT_DEV void shadow_on_hit(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
-    if (s.mode == 1) { shadow_finish(s, false, cnt); return; }       /* an earlier leaf returns a result beyond the light */
-    if (s.visited == 0) { shadow_finish(s, true, cnt); return; }
-    shadow_restart(sc, s, 1, s.visited);
+    if (s.ts & TS_MODE) { shadow_finish(s, false, cnt); return; }    /* an earlier leaf returns a result beyond the light */
+    const int visited = (int)TS_VISITED(s.ts);
+    if (visited == 0) { shadow_finish(s, true, cnt); return; }
+    shadow_restart(sc, s, 1, visited);
 }
 /* the top-level tables as k_shadow reads them: in global memory, or its LDS copy (generic pointers) */
 struct TopTables { const float4* tnodes; const uint2* tleaves; const uint32_t* titems; const float4* squares; const float4* spheres; const DMesh* meshes; };
@@ -769,7 +778,7 @@ RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane
                 DMesh m = tt.meshes[ord - sc.n_squares - sc.n_spheres];
                 /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter - slack > bound*1.00002 is
                  * still conservative and costs one compare per child */
-                s.prune_t = s.mode == 0 ? s.bound * 1.00002f : INFINITY;
+                s.prune_t = (s.ts & TS_MODE) == 0u ? s.bound * 1.00002f : INFINITY;
                 s.prune_raw = s.prune_t;
                 if (QUANT) s.prune_t = fminf(100.0f, s.prune_t);     /* tMax of AABB::intersect */
                 else s.maxinv = max_abs_inv(s.r);
@@ -791,10 +800,11 @@ RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane
             }
             continue;
         }
-        if (s.leaf_open) { s.leaf_open = 0; s.visited++; }
+        if (s.ts & TS_OPEN) s.ts = (s.ts & ~TS_OPEN) + TS_VISITED_ONE;
         if (s.tlink == LINK_NONE) {
-            if (s.tsp == 0) { shadow_finish(s, s.mode == 1, cnt); return; }   /* mode 0: no occluder; mode 1: nothing hides it */
-            s.tlink = stk[lds_index(--s.tsp, stride)];
+            if (TS_SP(s.ts) == 0u) { shadow_finish(s, (s.ts & TS_MODE) != 0u, cnt); return; }   /* mode 0: no occluder; mode 1: nothing hides it */
+            s.ts -= TS_SP_ONE;
+            s.tlink = stk[lds_index((int)TS_SP(s.ts), stride)];
         }
         if (s.tlink >= 0) {
             const float4* nd = tt.tnodes + 4 * (size_t)s.tlink;
@@ -803,14 +813,14 @@ RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane
             bool hL = slab(s.r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
             bool hR = slab(s.r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
             int left = __float_as_int(d.x), right = __float_as_int(d.y);
-            if (hL && hR) { stk[lds_index(s.tsp++, stride)] = right; s.tlink = left; }
+            if (hL && hR) { stk[lds_index((int)TS_SP(s.ts), stride)] = right; s.ts += TS_SP_ONE; s.tlink = left; }
             else if (hL) s.tlink = left;
             else if (hR) s.tlink = right;
             else s.tlink = LINK_NONE;
         } else {
-            if (s.mode == 1 && s.visited >= s.limit) { shadow_finish(s, true, cnt); return; }
+            if ((s.ts & TS_MODE) && TS_VISITED(s.ts) >= TS_LIMIT(s.ts)) { shadow_finish(s, true, cnt); return; }
             uint2 lf = tt.tleaves[-1 - s.tlink];
-            s.top_pos = lf.x; s.top_end = lf.x + lf.y; s.leaf_open = 1;
+            s.top_pos = lf.x; s.top_end = lf.x + lf.y; s.ts |= TS_OPEN;
             s.tlink = LINK_NONE;
         }
     }
@@ -1101,7 +1111,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             if (s.st == ST_IDLE && idx < total) {
                 s.key = (uint32_t)(idx / (unsigned)S);
                 float4 ro = rays[2 * idx], rd = rays[2 * idx + 1];
-                s.lightDistance = ro.w;
+                s.bound = ro.w;                                                       /* lightDistance */
                 s.r.o = f3(ro.x, ro.y, ro.z);
                 s.r.d = f3(rd.x, rd.y, rd.z);
                 s.r.inv = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);                 /* AccelerationStruct.cpp:19 */

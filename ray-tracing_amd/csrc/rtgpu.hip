@@ -742,6 +742,7 @@ int check_desc(rt_ctx* c, const rt_scene_desc* d) {
                 if (d->tri_indices[3 * (m.tri_first + i) + k] >= (uint64_t)m.vert_count) return fail(c, RT_ERR_ARG, "mesh %d: vertex index out of range", mi);
         }
     }
+    if (d->top_depth > 60 || d->n_top_leaves > 4000) return fail(c, RT_ERR_LIMIT, "top-level tree too deep or too wide (k_shadow packs its top-level state)");
     if (d->n_tris > 0x1FFFFFF0ll || d->n_mesh_nodes > 0x7FFFFFF0ll || d->n_mesh_leaves > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "scene too large for 32-bit links");
     return RT_OK;
 }
