@@ -27,6 +27,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 #include <utility>
 
@@ -106,6 +107,18 @@ int upload(rt_ctx* c, const std::vector<T>& v, const T** out) {
     c->scene_bufs.push_back(b);
     *out = static_cast<const T*>(b.p);
     return RT_OK;
+}
+
+/* upload-time loops over millions of triangles: split over a few host threads (the per-item work is independent) */
+template <typename F>
+void parallel_for(int64_t n, F body) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), n / 65536 + 1);
+    if (const char* e = getenv("OMP_NUM_THREADS")) nt = std::max(1, std::min(nt, atoi(e)));
+    if (nt <= 1) { body((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([=] { body(n * t / nt, n * (t + 1) / nt); });
+    for (auto& x : th) x.join();
 }
 
 /* host float helpers in the reference's operation order (this file is built with -ffp-contract=off) */
@@ -362,7 +375,7 @@ double tri_excursion(const H3& c0, const H3& c1, const H3& c2, float area_f) {
         const double G = G0 + Gs * rho;
         const double next = 2.0 * G / h + std::sqrt(2.0 * a * G + G * G) / l;
         if (!(next < 1e30)) return INFINITY;
-        if (next <= rho * (1.0 + 1e-12)) break;
+        if (next <= rho * 1.001) { rho = next; break; }       /* (the slope is below 1/4: what is left is below 0.04 % of rho) */
         rho = next;
     }
     return 2.0 * rho;
@@ -865,7 +878,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
         float amax = 0.f;
         for (int64_t v = 0; v < 3 * m.vert_count; v++) amax = std::max(amax, std::fabs(d->positions[3 * m.vert_first + v]));
         texc.assign((size_t)m.tri_count, 0.f);
-        for (int64_t j = 0; j < m.tri_count; j++) {
+        parallel_for(m.tri_count, [&](int64_t j_lo, int64_t j_hi) {
+        for (int64_t j = j_lo; j < j_hi; j++) {
             uint32_t t = d->mesh_items[m.tri_first + j];
             const uint32_t* iv = d->tri_indices + 3 * (m.tri_first + t);
             H3 c0, c1, c2;
@@ -891,6 +905,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
             ids[g] = make_uint4((uint32_t)(m.vert_first + iv[0]), (uint32_t)(m.vert_first + iv[1]), (uint32_t)(m.vert_first + iv[2]), t);
             texc[(size_t)j] = (float)(tri_excursion(c0, c1, c2, area) + 1e-5 * (double)amax + 1e-6);
         }
+        });
         auto glob = [&](int32_t link) {
             if (link >= 0) return (int32_t)(link + m.node_first);
             const rt_bvh_leaf& lf = d->mesh_leaves[m.leaf_first + (-1 - link)];
