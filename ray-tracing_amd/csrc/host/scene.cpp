@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <thread>
 
 namespace rth {
 
@@ -256,6 +257,54 @@ static int32_t buildNode(FlatTree& t, BuildRec* a, size_t lo, size_t hi, int dee
     return me;
 }
 
+/* The triangle tree of a big mesh on several threads, same result: the two halves of a node are independent once the
+ * node's partition is done, so large halves are built into fragments of their own (left half on a new thread) and
+ * appended in the order the sequential recursion emits them -- node, left subtree, right subtree -- with the links
+ * moved by the fragment's place. */
+static void appendFragment(FlatTree& t, const FlatTree& f, int32_t& link) {
+    const int32_t node0 = (int32_t)t.nodes.size(), leaf0 = (int32_t)t.leaves.size();
+    const uint32_t item0 = (uint32_t)t.items.size();
+    auto moved = [&](int32_t l) { return l >= 0 ? l + node0 : l - leaf0; };
+    for (rt_bvh_node n : f.nodes) { n.left = moved(n.left); n.right = moved(n.right); t.nodes.push_back(n); }
+    for (rt_bvh_leaf lf : f.leaves) { lf.first += item0; t.leaves.push_back(lf); }
+    t.items.insert(t.items.end(), f.items.begin(), f.items.end());
+    t.depth = std::max(t.depth, f.depth);
+    link = moved(link);
+}
+static int32_t buildNodeParallel(FlatTree& t, BuildRec* a, size_t lo, size_t hi, int deepLimit, const AABB& box, int level, int threadsLeft) {
+    const size_t n = hi - lo;
+    int unused = 0;
+    if (threadsLeft <= 1 || n < 200000 || !(deepLimit > 0 && n > 1)) return buildNode(t, a, lo, hi, deepLimit, box, 0, unused, level);
+    Vec3 diag = box.max - box.min;
+    const int axis = diag[0] > std::max(diag[1], diag[2]) ? 0 : diag[1] > diag[2] ? 1 : 2;       /* AccelerationStruct.cpp:160 */
+    Vec3 center = box.min + diag / 2.f;
+    const float pivot = center[axis];
+    const size_t mid = split(a, lo, hi, [axis, pivot](const BuildRec& r) { return r.c[axis] < pivot; });
+    const int32_t me = (int32_t)t.nodes.size();
+    t.nodes.emplace_back();
+    std::memset(&t.nodes[me], 0, sizeof(rt_bvh_node));
+    AABB lb, rb;
+    FlatTree lf, rf;
+    for (FlatTree* f : {&lf, &rf}) {        /* one allocation each (growing a vector of this size step by step is mostly page faults) */
+        const size_t cnt = f == &lf ? mid - lo : hi - mid;
+        f->nodes.reserve(cnt); f->leaves.reserve(cnt + 1); f->items.reserve(cnt);
+    }
+    int32_t l = 0, r = 0;
+    std::thread left([&] {
+        if (mid - lo >= 1) { lb = unionBox(a, lo, mid); l = buildNodeParallel(lf, a, lo, mid, deepLimit - 1, lb, level + 1, threadsLeft / 2); }
+        else { int u = 0; l = buildNode(lf, a, lo, lo, 0, lb, 0, u, level + 1); }
+    });
+    if (hi - mid >= 1) { rb = unionBox(a, mid, hi); r = buildNodeParallel(rf, a, mid, hi, deepLimit - 1, rb, level + 1, threadsLeft - threadsLeft / 2); }
+    else { int u = 0; r = buildNode(rf, a, mid, mid, 0, rb, 0, u, level + 1); }
+    left.join();
+    appendFragment(t, lf, l);
+    appendFragment(t, rf, r);
+    storeBoxes(t.nodes[me], lb, rb);
+    t.nodes[me].left = l;
+    t.nodes[me].right = r;
+    return me;
+}
+
 void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out) {
     out = FlatTree();
     const size_t nt = triangles.size() / 3;
@@ -280,9 +329,12 @@ void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& t
             box.max[k] = p[k] > box.max[k] ? p[k] : box.max[k];
         }
     out.rootBox = box;
-    out.items.reserve(nt);
-    int unused = 0;
-    out.root = buildNode(out, recs.data(), 0, nt, deepLimit, box, 0, unused, 0);
+    out.items.reserve(nt); out.nodes.reserve(nt); out.leaves.reserve(nt + 1);
+    const auto T0 = std::chrono::steady_clock::now();
+    int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (const char* e = getenv("OMP_NUM_THREADS")) threads = std::max(1, std::min(threads, atoi(e)));
+    out.root = buildNodeParallel(out, recs.data(), 0, nt, deepLimit, box, 0, threads);
+    if (getenv("RTH_TIMING")) fprintf(stderr, "[rthost] tree of %zu triangles, depth limit %d, %d threads: %.3f s\n", nt, deepLimit, threads, std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
 }
 
 void buildBVH(const std::vector<AABB>& objectBoxes, int deepLimit, FlatTree& out) {

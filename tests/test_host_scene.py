@@ -183,3 +183,16 @@ def test_interleaved_tiles_partition_the_image(rt):
                 seen[y:y + th, x:x + tw] += 1
         assert np.all(seen == 1)
         assert max(per_rank) - min(per_rank) <= 1
+
+
+def test_threaded_tree_build_equals_the_sequential_one(rt, monkeypatch):
+    """buildBVH on several threads (meshes of 200 000 triangles and more: fragments appended in the order the
+    recursion emits them) gives the tree of the one-thread build, bit for bit."""
+    monkeypatch.setenv("OMP_NUM_THREADS", "1")
+    a = rt.HostScene("soup:500000", 3, 22).arrays()
+    monkeypatch.setenv("OMP_NUM_THREADS", "8")
+    b = rt.HostScene("soup:500000", 3, 22).arrays()
+    for k in ("mesh_items", "mesh_nodes", "mesh_leaves", "top_nodes", "top_leaves", "top_items"):
+        assert a[k].tobytes() == b[k].tobytes(), k
+    assert len(a["mesh_nodes"]) > 200000
+    assert (a["meshes"][0].root, a["meshes"][0].depth) == (b["meshes"][0].root, b["meshes"][0].depth)
