@@ -229,8 +229,10 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
     monkeypatch.delenv("RT_WIDE_LDS_CAP")
     assert np.array_equal(bits(spilled), bits(quant)) and sst.rays_shadow == qst.rays_shadow
     # fat leaves walked triangle by triangle (no sub-trees), and sub-trees in every leaf of more than 6 triangles
-    for knob in ("RT_NO_LEAF_SPLIT", "RT_FORCE_LEAF_SPLIT"):
-        monkeypatch.setenv(knob, "1")
+    # ... and top-level rounds of k_shadow that never wait / wait for 48 lanes, top-level tables read from global memory
+    for knob, value in (("RT_NO_LEAF_SPLIT", "1"), ("RT_FORCE_LEAF_SPLIT", "1"), ("RT_TOP_MIN", "1"), ("RT_TOP_MIN", "48"),
+                        ("RT_TOP_GLOBAL", "1")):
+        monkeypatch.setenv(knob, value)
         c5 = rt.Context(0)
         try:
             c5.upload_scene(hs)
@@ -238,7 +240,7 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
         finally:
             c5.close()
         monkeypatch.delenv(knob)
-        assert np.array_equal(bits(other), bits(quant)) and np.array_equal(oprim, qprim) and ost.rays_shadow == qst.rays_shadow, knob
+        assert np.array_equal(bits(other), bits(quant)) and np.array_equal(oprim, qprim) and ost.rays_shadow == qst.rays_shadow, (knob, value)
     # shrink one child box of a mesh root below its own children's boxes: not nested any more
     dp = hs.desc
     d = dp.contents
