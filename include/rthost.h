@@ -83,6 +83,7 @@ public:
     FlatTree triangleTree;
 
     bool loadOFF(const std::string& filename);          /* Mesh.cpp:5-23 */
+    bool loadOFFColoured(const std::string& filename);  /* OFF and COFF (per-vertex colour columns are skipped), faces of any size fanned into triangles; scene files only */
     void recomputeNormals();                            /* Mesh.cpp:25-38 */
     void centerAndScaleToUnit();                        /* Mesh.cpp:40-53 */
     void translate(const Vec3& t);                      /* Mesh.h:128-132 */
@@ -156,6 +157,15 @@ public:
     bool setup_soup_scene(int64_t ntris);               /* BASELINE config 5 */
     bool setup(const std::string& name);
 
+    /* Scene description files (data-driven scenes instead of the hard-coded setup_* tables; the
+     * reference has no such format). Text lines -- light / texture / square / sphere / mesh with the material inline --
+     * where a mesh is either an OFF file plus the transformations of Mesh.h:128-173 (mesh_off, center_unit, scale,
+     * rotate_x/y/z, translate), or a binary block of final positions and triangles in the file itself (the mesh
+     * cache for large inputs; textures likewise). save() writes the second form and reproduces the scene exactly:
+     * load(save(s)) flattens to the same bytes as s. load() returns false and sets *why on malformed input. */
+    bool save(const std::string& filename) const;
+    bool load(const std::string& filename, std::string* why = nullptr);
+
     /* Flatten into the rt_scene_desc layout; the returned desc points into this object. */
     const rt_scene_desc& flatten();
 
@@ -210,6 +220,9 @@ int rth_build(rth_scene*, int top_depth, int mesh_depth);
 const rt_scene_desc* rth_scene_desc(rth_scene*);
 int rth_ray_trace_from_camera(rt_ctx*, rth_scene*, const rt_camera*, const rt_render_params*, const char* ppm_path, double* seconds);
 int rth_write_ppm(const char* path, const float* rgb, int w, int h);
+/* Scene::save / Scene::load (scene description files, see rthost.h); load replaces the scene's contents, rth_build comes after. */
+int rth_scene_save(rth_scene*, const char* path);
+int rth_scene_load(rth_scene*, const char* path);
 int rth_load_off(const char* path, float* verts, int64_t max_v, uint32_t* tris, int64_t max_t, int64_t* nv, int64_t* nt);
 
 #ifdef __cplusplus

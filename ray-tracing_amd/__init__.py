@@ -113,7 +113,7 @@ EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set
            "rt_intersect", "rt_occluded", "rt_trace", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
            "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_scene_desc",
-           "rth_ray_trace_from_camera", "rth_write_ppm", "rth_load_off"]
+           "rth_ray_trace_from_camera", "rth_write_ppm", "rth_load_off", "rth_scene_save", "rth_scene_load"]
 
 _lib = None
 
@@ -174,6 +174,8 @@ def lib():
                                             C.POINTER(C.c_double)]
     L.rth_write_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     L.rth_load_off.argtypes = [C.c_char_p, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)]
+    L.rth_scene_save.argtypes = [vp, C.c_char_p]
+    L.rth_scene_load.argtypes = [vp, C.c_char_p]
     L.rth_set_asset_dir(DEFAULT_ASSET_DIR.encode())
     L.rth_set_image_dir(DEFAULT_IMAGE_DIR.encode())
     _lib = L
@@ -228,6 +230,21 @@ class HostScene:
             if rc != RT_OK:
                 raise RtError(f"rth_scene_setup({name!r}) failed ({rc}); asset dir ok?")
             self.build(top_depth, mesh_depth)
+
+    @classmethod
+    def from_file(cls, path, top_depth=3, mesh_depth=12):
+        """A scene description file (rthost.h, Scene::load), built like a named scene."""
+        s = cls()
+        rc = s.L.rth_scene_load(s.h, os.fsencode(path))
+        if rc != RT_OK:
+            raise RtError(f"rth_scene_load({path!r}) failed ({rc})")
+        s.build(top_depth, mesh_depth)
+        return s
+
+    def save(self, path):
+        rc = self.L.rth_scene_save(self.h, os.fsencode(path))
+        if rc != RT_OK:
+            raise RtError(f"rth_scene_save({path!r}) failed ({rc})")
 
     def __del__(self):
         try:

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <sstream>
 #include <thread>
 
 namespace rth {
@@ -573,6 +574,180 @@ bool Scene::setup_final_scene() {
     return true;
 }
 
+/* ------------------------------------------------------------------ scene description files (rthost.h) */
+bool Mesh::loadOFFColoured(const std::string& filename) {
+    std::ifstream in(filename.c_str());
+    if (!in) return false;
+    std::string header;
+    size_t nv = 0, nf = 0, ne = 0;
+    in >> header >> nv >> nf >> ne;
+    if (!in || (header != "OFF" && header != "COFF")) return false;
+    const bool coloured = header == "COFF";
+    positions.assign(nv, Vec3());
+    triangles.clear();
+    for (size_t i = 0; i < nv; i++) {
+        in >> positions[i][0] >> positions[i][1] >> positions[i][2];
+        if (coloured) { float c; in >> c >> c >> c >> c; }
+    }
+    for (size_t f = 0; f < nf; f++) {
+        size_t k = 0;
+        in >> k;
+        if (!in || k < 3) return false;
+        std::vector<uint32_t> idx(k);
+        for (size_t j = 0; j < k; j++) { in >> idx[j]; if (idx[j] >= nv) return false; }
+        for (size_t j = 1; j + 1 < k; j++) { triangles.push_back(idx[0]); triangles.push_back(idx[j]); triangles.push_back(idx[j + 1]); }
+        std::string rest;
+        std::getline(in, rest);                    /* optional face colour */
+    }
+    return (bool)in || in.eof();
+}
+
+static void writeMaterial(FILE* f, const Material& m) {
+    fprintf(f, " material %.9g %.9g %.9g  %.9g %.9g %.9g  %.9g %.9g %.9g  %.17g %d %.9g %.9g %.9g %d %d %.17g\n",
+            m.ambient_material[0], m.ambient_material[1], m.ambient_material[2], m.diffuse_material[0], m.diffuse_material[1], m.diffuse_material[2],
+            m.specular_material[0], m.specular_material[1], m.specular_material[2], m.shininess, m.type, m.index_medium, m.transparency,
+            m.reflectivity, m.texture, m.normalMap, m.materialScale);
+}
+static bool readMaterial(std::istringstream& in, Material& m, size_t n_textures) {
+    std::string word;
+    in >> word;
+    if (word != "material") return false;
+    for (int k = 0; k < 3; k++) in >> m.ambient_material[k];
+    for (int k = 0; k < 3; k++) in >> m.diffuse_material[k];
+    for (int k = 0; k < 3; k++) in >> m.specular_material[k];
+    in >> m.shininess >> m.type >> m.index_medium >> m.transparency >> m.reflectivity >> m.texture >> m.normalMap >> m.materialScale;
+    if (!in) return false;
+    return m.texture < (int)n_textures && m.normalMap < (int)n_textures && m.type >= 0 && m.type <= 3;
+}
+
+bool Scene::save(const std::string& filename) const {
+    FILE* f = fopen(filename.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "rtscene 1\n");
+    for (const Image& im : textures) {             /* first: materials refer to them by index */
+        fprintf(f, "texture %d %d %d\n", im.width, im.height, im.channels);
+        fwrite(im.data.data(), 1, im.data.size(), f);
+        fputc('\n', f);
+    }
+    for (const Light& l : lights)
+        fprintf(f, "light %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", l.pos[0], l.pos[1], l.pos[2], l.radius, l.material[0], l.material[1], l.material[2]);
+    for (const Square& q : squares) {
+        fprintf(f, "square");
+        for (int v = 0; v < 4; v++) fprintf(f, " %.9g %.9g %.9g", q.vertices[v][0], q.vertices[v][1], q.vertices[v][2]);
+        writeMaterial(f, q.material);
+    }
+    for (const Sphere& sp : spheres) {
+        fprintf(f, "sphere %.9g %.9g %.9g %.9g", sp.m_center[0], sp.m_center[1], sp.m_center[2], sp.m_radius);
+        writeMaterial(f, sp.material);
+    }
+    for (const Mesh& m : meshes) {
+        fprintf(f, "mesh %zu %zu", m.positions.size(), m.triangleCount());
+        writeMaterial(f, m.material);
+        fwrite(m.positions.data(), sizeof(Vec3), m.positions.size(), f);
+        fwrite(m.triangles.data(), sizeof(uint32_t), m.triangles.size(), f);
+        fputc('\n', f);
+    }
+    fprintf(f, "end\n");
+    return fclose(f) == 0;
+}
+
+bool Scene::load(const std::string& filename, std::string* why) {
+    auto fail = [&](const std::string& what) { if (why) *why = what; clear(); return false; };
+    std::ifstream in(filename.c_str(), std::ios::binary);
+    if (!in) return fail("cannot open " + filename);
+    clear();
+    std::string line;
+    if (!std::getline(in, line) || line.rfind("rtscene 1", 0) != 0) return fail("not an rtscene 1 file");
+    Mesh* last = nullptr;                          /* the mesh the transformation lines apply to */
+    bool ended = false;
+    int lineno = 1;
+    auto block = [&](void* dst, size_t bytes) {    /* a binary block follows its line and ends with a newline */
+        in.read(static_cast<char*>(dst), (std::streamsize)bytes);
+        return (size_t)in.gcount() == bytes && in.get() == '\n';
+    };
+    while (!ended && std::getline(in, line)) {
+        lineno++;
+        std::istringstream ls(line);
+        std::string kind;
+        ls >> kind;
+        const std::string at = " (line " + std::to_string(lineno) + ")";
+        if (kind.empty() || kind[0] == '#') continue;
+        if (kind == "end") ended = true;
+        else if (kind == "texture") {
+            Image im;
+            std::string path;
+            ls >> path;
+            if (!path.empty() && (path[0] < '0' || path[0] > '9')) {          /* texture <file.ppm under the image directory> */
+                if (loadImage(path) < 0) return fail("cannot read image " + path + at);
+                continue;
+            }
+            std::istringstream dims(line);
+            dims >> kind >> im.width >> im.height >> im.channels;
+            if (!dims || im.width <= 0 || im.height <= 0 || im.channels < 3 || im.channels > 4 || (int64_t)im.width * im.height > (1ll << 28)) return fail("bad texture header" + at);
+            im.data.resize((size_t)im.width * im.height * im.channels);
+            if (!block(im.data.data(), im.data.size())) return fail("truncated texture" + at);
+            textures.push_back(std::move(im));
+        } else if (kind == "light") {
+            Light l;
+            ls >> l.pos[0] >> l.pos[1] >> l.pos[2] >> l.radius >> l.material[0] >> l.material[1] >> l.material[2];
+            if (!ls) return fail("bad light" + at);
+            lights.push_back(l);
+        } else if (kind == "square") {
+            Square q;
+            for (int v = 0; v < 4; v++) ls >> q.vertices[v][0] >> q.vertices[v][1] >> q.vertices[v][2];
+            if (!ls || !readMaterial(ls, q.material, textures.size())) return fail("bad square" + at);
+            squares.push_back(q);
+        } else if (kind == "sphere") {
+            Sphere sp;
+            ls >> sp.m_center[0] >> sp.m_center[1] >> sp.m_center[2] >> sp.m_radius;
+            if (!ls || !readMaterial(ls, sp.material, textures.size())) return fail("bad sphere" + at);
+            spheres.push_back(sp);
+        } else if (kind == "mesh") {
+            size_t nv = 0, nt = 0;
+            ls >> nv >> nt;
+            Material mat;
+            if (!ls || nv == 0 || nt == 0 || nv > (1ull << 31) || nt > (1ull << 29) || !readMaterial(ls, mat, textures.size())) return fail("bad mesh header" + at);
+            meshes.emplace_back();
+            Mesh& m = meshes.back();
+            m.material = mat;
+            m.positions.resize(nv);
+            m.triangles.resize(3 * nt);
+            in.read(reinterpret_cast<char*>(m.positions.data()), (std::streamsize)(nv * sizeof(Vec3)));      /* positions and triangles are one block */
+            if ((size_t)in.gcount() != nv * sizeof(Vec3) || !block(m.triangles.data(), 3 * nt * sizeof(uint32_t))) return fail("truncated mesh" + at);
+            for (uint32_t i : m.triangles) if (i >= nv) return fail("triangle index out of range" + at);
+            m.build_arrays();
+            last = &m;
+        } else if (kind == "mesh_off") {
+            std::string path;
+            ls >> path;
+            Material mat;
+            if (!ls || !readMaterial(ls, mat, textures.size())) return fail("bad mesh_off" + at);
+            meshes.emplace_back();
+            Mesh& m = meshes.back();
+            m.material = mat;
+            if (!m.loadOFFColoured(g_asset_dir + "/" + path) || m.positions.empty() || m.triangles.empty()) return fail("cannot read OFF file " + path + at);
+            m.build_arrays();
+            last = &m;
+        } else if (kind == "center_unit" || kind == "scale" || kind == "translate" || kind == "rotate_x" || kind == "rotate_y" || kind == "rotate_z") {
+            if (!last) return fail(kind + " without a mesh" + at);
+            float a = 0.f, b = 0.f, c = 0.f;
+            if (kind == "center_unit") last->centerAndScaleToUnit();
+            else if (kind == "scale" || kind == "translate") {
+                ls >> a >> b >> c;
+                if (!ls) return fail("bad " + kind + at);
+                if (kind == "scale") last->scale(Vec3(a, b, c)); else last->translate(Vec3(a, b, c));
+            } else {
+                ls >> a;
+                if (!ls) return fail("bad " + kind + at);
+                if (kind == "rotate_x") last->rotate_x(a); else if (kind == "rotate_y") last->rotate_y(a); else last->rotate_z(a);
+            }
+            last->build_arrays();                   /* normals follow the positions, as after every setup_* block */
+        } else return fail("unknown entry '" + kind + "'" + at);
+    }
+    if (!ended) return fail("no end line: truncated file");
+    return true;
+}
+
 /* Counter RNG of rtgpu (rt_rng) drives the synthetic soup so that both sides of the
  * boundary can generate it without files. */
 static float unit24(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
@@ -823,6 +998,13 @@ int rth_ray_trace_from_camera(rt_ctx* ctx, rth_scene* s, const rt_camera* cam, c
     return rth::ray_trace_from_camera(ctx, s->scene, c, p->img_w, p->img_h, p, path, seconds);
 }
 int rth_write_ppm(const char* path, const float* rgb, int w, int h) { return rth::write_ppm(path, rgb, w, h); }
+int rth_scene_save(rth_scene* s, const char* path) { return (s && path && s->scene.save(path)) ? RT_OK : RT_ERR_ARG; }
+int rth_scene_load(rth_scene* s, const char* path) {
+    if (!s || !path) return RT_ERR_ARG;
+    std::string why;
+    if (!s->scene.load(path, &why)) { fprintf(stderr, "[rthost] %s\n", why.c_str()); return RT_ERR_ARG; }
+    return RT_OK;
+}
 int rth_load_off(const char* path, float* verts, int64_t max_v, uint32_t* tris, int64_t max_t, int64_t* nv, int64_t* nt) {
     rth::Mesh m;
     if (!m.loadOFF(path)) return RT_ERR_ARG;

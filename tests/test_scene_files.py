@@ -1,0 +1,93 @@
+"""Scene description files (rthost.h Scene::save / Scene::load): a saved scene loads back to the same
+flattened bytes; a hand-written file with OFF / COFF meshes and the Mesh transformations equals the same scene built
+through the API; malformed files are refused."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+rt = importlib.import_module("ray-tracing_amd")
+
+ARRAYS = ("positions", "normals", "tris", "mesh_items", "mesh_nodes", "mesh_leaves", "top_nodes", "top_leaves", "top_items")
+
+
+def raw(x):
+    return bytes(memoryview(x).cast("B")) if not isinstance(x, np.ndarray) else x.tobytes()
+
+
+def same_scene(a, b):
+    A, B = a.arrays(), b.arrays()
+    for k in ARRAYS:
+        assert A[k].tobytes() == B[k].tobytes(), k
+    for k in ("meshes", "spheres", "squares", "lights", "materials"):
+        assert len(A[k]) == len(B[k]), k
+        for x, y in zip(A[k], B[k]):
+            assert C.string_at(C.addressof(x), C.sizeof(x)) == C.string_at(C.addressof(y), C.sizeof(y)), k
+    assert len(A["textures"]) == len(B["textures"])
+    for x, y in zip(A["textures"], B["textures"]):
+        assert np.array_equal(x, y)
+    assert A["top_root"] == B["top_root"]
+
+
+@pytest.mark.parametrize("name,depth", [("final", 12), ("refraction", 12), ("reflexion_chamber", 12), ("mesh_cow", 16), ("soup:30000", 20)])
+def test_saved_scene_loads_back_identically(tmp_path, name, depth):
+    a = rt.HostScene(name, 3, depth)
+    path = tmp_path / "scene.rtscene"
+    a.save(path)
+    b = rt.HostScene.from_file(path, 3, depth)
+    same_scene(a, b)
+    b.save(tmp_path / "again.rtscene")
+    assert (tmp_path / "again.rtscene").read_bytes() == path.read_bytes()
+
+
+MATERIAL = "material 0 0 0  0.8 0.6 0.4  0.5 0.5 0.5  16 0 1 0 0 -1 -1 1"
+
+
+def test_hand_written_scene_with_off_meshes_and_transformations(tmp_path, monkeypatch):
+    models = tmp_path / "models"
+    models.mkdir()
+    (models / "quad.off").write_text("OFF\n4 1 0\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    (models / "tet.off").write_text("COFF\n4 4 6\n0 0 0 255 0 0 255\n1 0 0 0 255 0 255\n0 1 0 0 0 255 255\n0 0 1 9 9 9 255\n"
+                                    "3 0 2 1\n3 0 1 3  0.5 0.5 0.5\n3 1 2 3\n3 0 3 2\n")
+    L = rt.lib()
+    L.rth_set_asset_dir(os.fsencode(models))
+    try:
+        (tmp_path / "s.rtscene").write_text(
+            "rtscene 1\n# a comment\nlight 0 5 1 0.25 1 1 1\n"
+            f"square -3 -1 3  3 -1 3  3 -1 -3  -3 -1 -3 {MATERIAL}\n"
+            f"sphere 0.5 0.25 -1 0.75 {MATERIAL}\n"
+            f"mesh_off quad.off {MATERIAL}\nscale 2 2 2\nrotate_y 30\ntranslate 0 0.5 -2\n"
+            f"mesh_off tet.off {MATERIAL}\ncenter_unit\nrotate_x 20\nrotate_z 10\n"
+            "end\n")
+        a = rt.HostScene.from_file(tmp_path / "s.rtscene", 2, 6)
+        A = a.arrays()
+        assert [int(m.tri_count) for m in A["meshes"]] == [2, 4] and len(A["spheres"]) == 1 and len(A["squares"]) == 1
+        assert np.isfinite(A["positions"]).all() and np.isfinite(A["normals"]).all()
+        assert np.allclose(A["positions"][:4, 1], 0.5 + 2 * np.array([0, 0, 1, 1]), atol=1e-6)      # scaled, turned about y, lifted
+        # the saved form of it is the same scene
+        a.save(tmp_path / "t.rtscene")
+        same_scene(a, rt.HostScene.from_file(tmp_path / "t.rtscene", 2, 6))
+    finally:
+        L.rth_set_asset_dir(rt.DEFAULT_ASSET_DIR.encode())
+
+
+@pytest.mark.parametrize("text", [
+    "", "rtscene 2\nend\n", "rtscene 1\nlight 0 0\nend\n", "rtscene 1\nsphere 0 0 0 1\nend\n", "rtscene 1\nteapot\nend\n",
+    "rtscene 1\nlight 0 5 1 0.25 1 1 1\n", "rtscene 1\nscale 1 1 1\nend\n", f"rtscene 1\nmesh_off nowhere.off {MATERIAL}\nend\n",
+    f"rtscene 1\nmesh 3 1 {MATERIAL}\nshort\nend\n", f"rtscene 1\nsphere 0 0 0 1 {MATERIAL.replace('-1 -1 1', '4 -1 1')}\nend\n",
+    "rtscene 1\ntexture 4 4 3\nxx\nend\n"])
+def test_malformed_scene_files_are_refused(tmp_path, text):
+    p = tmp_path / "bad.rtscene"
+    p.write_text(text)
+    with pytest.raises(rt.RtError):
+        rt.HostScene.from_file(p)
+
+
+def test_mesh_block_with_a_bad_index_is_refused(tmp_path):
+    p = tmp_path / "bad.rtscene"
+    p.write_bytes(b"rtscene 1\nmesh 3 1 " + MATERIAL.encode() + b"\n" + np.zeros(9, np.float32).tobytes()
+                  + np.array([0, 1, 7], np.uint32).tobytes() + b"\nend\n")
+    with pytest.raises(rt.RtError):
+        rt.HostScene.from_file(p)
