@@ -27,6 +27,9 @@ struct PathState {          /* 64 B */
     int32_t remaining;      /* NRemainingBounces */
     uint32_t flags;         /* bit0: write prim id */
 };
+#ifndef RT_CBLOCK
+#define RT_CBLOCK 256       /* threads per block of k_closest: one append atomic per block */
+#endif
 struct DiffuseRec {         /* 64 B + code */
     float P[3], N[3], V[3], thr[3];
     uint32_t mat;           /* material index | checker override: bit30 set, bit29 = colour (0 black, 1 white) */
@@ -444,6 +447,32 @@ RT_DEV uint32_t wave_reserve(uint32_t* counter, uint32_t want) {
     return base + mine;
 }
 
+/* Block-aggregated append to the two queues of k_closest at once: every thread of the block calls this (no early
+ * exits before it) with its own request counts. All waves of all blocks used to hit the same two counters with
+ * returning atomics (plus two for the ray statistics): on scenes with cheap rays that contention, not the
+ * traversal, set the kernel's time. Now one 64-bit atomic per block reserves both ranges (n_child in the low word,
+ * n_diffuse in the high word of the same 8 bytes). s_tot: 2 * (waves per block) + 2 words of LDS. */
+RT_DEV void block_reserve2(Counters* ctr, uint32_t want_child, uint32_t want_diffuse, uint32_t* s_tot, uint32_t& cbase, uint32_t& dbase) {
+    const unsigned long long m1 = __ballot(want_child == 1), m2 = __ballot(want_child == 2), md = __ballot(want_diffuse != 0);
+    const int lane = __lane_id();
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t cmine = __popcll(m1 & lt) + 2u * __popcll(m2 & lt), ctot = __popcll(m1) + 2u * __popcll(m2);
+    const uint32_t dmine = __popcll(md & lt), dtot = __popcll(md);
+    const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+    if (lane == 0) { s_tot[2 * wave] = ctot; s_tot[2 * wave + 1] = dtot; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0, d = 0;
+        for (int w = 0; w < nwaves; w++) { uint32_t a = s_tot[2 * w], b = s_tot[2 * w + 1]; s_tot[2 * w] = c; s_tot[2 * w + 1] = d; c += a; d += b; }
+        unsigned long long base = 0ull;
+        if (c | d) base = atomicAdd(reinterpret_cast<unsigned long long*>(&ctr->n_child), (unsigned long long)c | ((unsigned long long)d << 32));
+        s_tot[2 * nwaves] = (uint32_t)base; s_tot[2 * nwaves + 1] = (uint32_t)(base >> 32);
+    }
+    __syncthreads();
+    cbase = s_tot[2 * nwaves] + s_tot[2 * wave] + cmine;
+    dbase = s_tot[2 * nwaves + 1] + s_tot[2 * wave + 1] + dmine;
+}
+
 /* ------------------------------------------------------------------ kernels */
 
 /* main.cpp:191-201 + matrixUtilities.h:198-222: one lane per (pixel, sample). */
@@ -523,7 +552,7 @@ __global__ void __launch_bounds__(256) k_seed(const float* org, const float* dir
 /* Scene::rayTraceRecursive (Scene.h:174-280) for one path state: the recursion is unrolled into
  * child states carrying a throughput (radiance is linear in the child radiance, Scene.h:229,263-271). */
 template <bool SUB>
-__global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
+__global__ void __launch_bounds__(RT_CBLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
                                                       uint32_t child_cap, DiffuseRec* drec, unsigned long long* dcode, uint32_t* dtex,
                                                       uint32_t diffuse_cap, Counters* ctr, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
     extern __shared__ __align__(16) int s_stack[];
@@ -647,16 +676,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_closest(DScene sc, const PathState
         }
     }
 
-    /* wave-uniform section: ray statistics and queue appends */
-    {
-        unsigned long long mp = __ballot(active && code == 1ull), ms = __ballot(active && code != 1ull);
-        if (__lane_id() == 0) {
-            if (mp) atomicAdd(&ctr->rays_primary, (unsigned long long)__popcll(mp));
-            if (ms) atomicAdd(&ctr->rays_secondary, (unsigned long long)__popcll(ms));
-        }
-    }
-    uint32_t cbase = wave_reserve(&ctr->n_child, want_child);
-    uint32_t dbase = wave_reserve(&ctr->n_diffuse, want_diffuse ? 1u : 0u);
+    /* queue appends (the ray statistics are the host's: it knows how many states of a batch are fresh primaries) */
+    uint32_t cbase, dbase;
+    block_reserve2(ctr, want_child, want_diffuse ? 1u : 0u, reinterpret_cast<uint32_t*>(s_stack + (size_t)sc.cstack_cap * blockDim.x), cbase, dbase);
     if (want_child && cbase + want_child <= child_cap) {
         for (uint32_t k = 0; k < want_child; k++)
             store_state(child + cbase + k, c_o[k], c_d[k], c_thr[k], slot, pixel, sample, c_code[k], remaining - 1, 0u);

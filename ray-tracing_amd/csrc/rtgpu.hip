@@ -222,6 +222,12 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
     unsigned long long done = 0;
     size_t lds = lds_bytes(c, RT_BLOCK);
     c->ev_used = 0;
+    /* threads per block of k_closest (one append atomic per block): big blocks where rays are cheap and the appends would
+     * dominate, one wave per block under deep mesh trees, where a block would wait for its slowest wave
+     * (64 / 128 / 256 threads: refraction scene 13.9 / 10.7 / 9.3 ms, gorilla 13.5 / 12.0 / 11.1, C5 reduced 25.6 / 28.0 / 28.6) */
+    const uint32_t cblock_light = (c->sc.stack_cap - c->sc.top_cap - 2 > 16) ? 64u : (uint32_t)RT_CBLOCK;
+    uint32_t cblock = cblock_light;
+    if (const char* e = getenv("RT_CBLOCK")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) cblock = (uint32_t)v; }
 
     while (done < src.total || top > 0) {
         /* 1. top up with fresh primaries */
@@ -246,8 +252,10 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         EventPair* e1 = next_event(c, 0);
         if (!e1) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
         HIP_TRY(c, hipEventRecord(e1->a, c->stream));
+        /* (a batch of bounced rays is the heavy, divergent kind: default scene 147 ms with one wave per block, 169 with four) */
+        if (!getenv("RT_CBLOCK")) cblock = (2ull * n_new >= nb) ? cblock_light : 64u;
         auto launch_closest = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((nb + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds_bytes_closest(c, RT_BLOCK), c->stream, c->sc, stack + base, nb,
+            hipLaunchKernelGGL(kern, dim3((nb + cblock - 1) / cblock), dim3(cblock), lds_bytes_closest(c, cblock) + (2 * (cblock / 64) + 2) * sizeof(uint32_t), c->stream, c->sc, stack + base, nb,
                                static_cast<PathState*>(c->child.p), 2 * B, static_cast<DiffuseRec*>(c->drec.p),
                                static_cast<unsigned long long*>(c->dcode.p), static_cast<uint32_t*>(c->dtex.p), B, d_ctr, acc, nonfinite, prim);
         };
@@ -257,6 +265,8 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
         uint32_t n_child = c->h_ctr->n_child, n_diff = c->h_ctr->n_diffuse;
+        c->stats.rays_primary += n_new;                 /* the fresh primaries sit on top of the stack: all of them are in this batch */
+        c->stats.rays_secondary += nb - n_new;
         if (c->debug) fprintf(stderr, "[rtgpu] iter %llu: new %u batch %u -> children %u diffuse %u (stack %zu)\n",
                               (unsigned long long)c->stats.iterations, n_new, nb, n_child, n_diff, top);
         if (n_child > 2 * B || n_diff > B) return fail(c, RT_ERR_LIMIT, "queue overflow (%u children, %u diffuse)", n_child, n_diff);
@@ -322,8 +332,6 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    c->stats.rays_primary += c->h_ctr->rays_primary;
-    c->stats.rays_secondary += c->h_ctr->rays_secondary;
     c->stats.rays_shadow += c->h_ctr->rays_shadow;
     c->stats.nonfinite += c->h_ctr->nonfinite;
     if (c->count_steps)

@@ -189,9 +189,11 @@ def test_threaded_tree_build_equals_the_sequential_one(rt, monkeypatch):
     """buildBVH on several threads (meshes of 200 000 triangles and more: fragments appended in the order the
     recursion emits them) gives the tree of the one-thread build, bit for bit."""
     monkeypatch.setenv("OMP_NUM_THREADS", "1")
-    a = rt.HostScene("soup:500000", 3, 22).arrays()
+    sa = rt.HostScene("soup:500000", 3, 22)              # (kept alive: the mesh records below are views into the scenes)
+    a = sa.arrays()
     monkeypatch.setenv("OMP_NUM_THREADS", "8")
-    b = rt.HostScene("soup:500000", 3, 22).arrays()
+    sb = rt.HostScene("soup:500000", 3, 22)
+    b = sb.arrays()
     for k in ("mesh_items", "mesh_nodes", "mesh_leaves", "top_nodes", "top_leaves", "top_items"):
         assert a[k].tobytes() == b[k].tobytes(), k
     assert len(a["mesh_nodes"]) > 200000
