@@ -459,6 +459,14 @@ RT_DEV void block_reserve2(Counters* ctr, uint32_t want_child, uint32_t want_dif
     const uint32_t cmine = __popcll(m1 & lt) + 2u * __popcll(m2 & lt), ctot = __popcll(m1) + 2u * __popcll(m2);
     const uint32_t dmine = __popcll(md & lt), dtot = __popcll(md);
     const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+    if (nwaves == 1) {                                   /* one wave per block: no LDS, no barrier */
+        unsigned long long base = 0ull;
+        if (lane == 0 && (ctot | dtot)) base = atomicAdd(reinterpret_cast<unsigned long long*>(&ctr->n_child), (unsigned long long)ctot | ((unsigned long long)dtot << 32));
+        base = __shfl(base, 0);
+        cbase = (uint32_t)base + cmine;
+        dbase = (uint32_t)(base >> 32) + dmine;
+        return;
+    }
     if (lane == 0) { s_tot[2 * wave] = ctot; s_tot[2 * wave + 1] = dtot; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -551,8 +559,8 @@ __global__ void __launch_bounds__(256) k_seed(const float* org, const float* dir
 
 /* Scene::rayTraceRecursive (Scene.h:174-280) for one path state: the recursion is unrolled into
  * child states carrying a throughput (radiance is linear in the child radiance, Scene.h:229,263-271). */
-template <bool SUB>
-__global__ void __launch_bounds__(RT_CBLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
+template <bool SUB, int BLOCK>      /* BLOCK: the largest block it is launched with (64 or RT_CBLOCK); the one-wave build is the better one for heavy rays */
+__global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
                                                       uint32_t child_cap, DiffuseRec* drec, unsigned long long* dcode, uint32_t* dtex,
                                                       uint32_t diffuse_cap, Counters* ctr, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
     extern __shared__ __align__(16) int s_stack[];

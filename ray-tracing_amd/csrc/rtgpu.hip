@@ -255,11 +255,12 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         /* (a batch of bounced rays is the heavy, divergent kind: default scene 147 ms with one wave per block, 169 with four) */
         if (!getenv("RT_CBLOCK")) cblock = (2ull * n_new >= nb) ? cblock_light : 64u;
         auto launch_closest = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((nb + cblock - 1) / cblock), dim3(cblock), lds_bytes_closest(c, cblock) + (2 * (cblock / 64) + 2) * sizeof(uint32_t), c->stream, c->sc, stack + base, nb,
+            hipLaunchKernelGGL(kern, dim3((nb + cblock - 1) / cblock), dim3(cblock), lds_bytes_closest(c, cblock) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, c->sc, stack + base, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
                                static_cast<PathState*>(c->child.p), 2 * B, static_cast<DiffuseRec*>(c->drec.p),
                                static_cast<unsigned long long*>(c->dcode.p), static_cast<uint32_t*>(c->dtex.p), B, d_ctr, acc, nonfinite, prim);
         };
-        if (c->sc.has_sub && c->sc.quant_ok) launch_closest(k_closest<true>); else launch_closest(k_closest<false>);
+        if (c->sc.has_sub && c->sc.quant_ok) { if (cblock == 64u) launch_closest(k_closest<true, 64>); else launch_closest(k_closest<true, RT_CBLOCK>); }
+        else { if (cblock == 64u) launch_closest(k_closest<false, 64>); else launch_closest(k_closest<false, RT_CBLOCK>); }
         HIP_TRY(c, hipEventRecord(e1->b, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
