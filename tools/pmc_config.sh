@@ -14,8 +14,8 @@ import csv, sys, glob, collections
 tot = collections.defaultdict(float)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"]
-        if n.startswith("void " + sys.argv[2]) or n.startswith(sys.argv[2]):
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if n == sys.argv[2]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
 print({k: f"{v:.4g}" for k, v in tot.items()})
 PY
