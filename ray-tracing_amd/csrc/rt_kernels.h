@@ -1035,12 +1035,9 @@ RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt
 /* Scene::sampleSphereLight's sample position + Scene::isInShadow's ray (Scene.h:115-126,161-164) for
  * every (record, light, sample), at full lane utilisation, 32 bytes per ray: (origin, lightDistance)
  * (direction, -). The persistent kernel's refill then is two coalesced loads. */
-__global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
-                                                      const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
-                                                      float4* __restrict__ rays) {
-    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
-    if (idx >= total) return;
+/* the shadow ray of (record, light, sample) number idx */
+RT_DEV void shadow_ray_of(const DScene& sc, const FrameD& fr, const DiffuseRec* __restrict__ drec, const unsigned long long* __restrict__ dcode,
+                          unsigned long long idx, int S, uint32_t& key_out, F3& o_out, F3& d_out, float& dist_out) {
     uint32_t key = (uint32_t)(idx / (unsigned)S);
     uint32_t i = (uint32_t)(idx % (unsigned)S);
     uint32_t rec = key / (uint32_t)sc.n_lights, li = key % (uint32_t)sc.n_lights;
@@ -1066,8 +1063,52 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
     dir = normalized(dir);
     F3 o = add(P, mul(0.001f, dir));
     F3 d = normalized(dir);                                                          /* Line.h:15 */
+    key_out = key; o_out = o; d_out = d; dist_out = lightDistance;
+}
+__global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
+                                                      const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
+                                                      float4* __restrict__ rays) {
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    if (idx >= total) return;
+    uint32_t key; F3 o, d; float lightDistance;
+    shadow_ray_of(sc, fr, drec, dcode, idx, S, key, o, d, lightDistance);
     rays[2 * idx] = make_float4(o.x, o.y, o.z, lightDistance);
     rays[2 * idx + 1] = make_float4(d.x, d.y, d.z, 0.f);
+}
+
+/* Scenes without meshes (the refraction and reflexion scenes: a sphere and a wall): a shadow ray is a handful of object
+ * tests, and the persistent kernel's machinery -- ray buffer, refill, phases -- costs more than the rays (PMC on the
+ * refraction scene: a quarter of the lanes active, the rest waiting for the next rays to arrive). Here every ray is
+ * one thread from its diffuse record to its verdict (Scene::isInShadow through occluded()), no ray buffer; the lanes
+ * of a wave that share a (record, light) pair add their occluded samples with one atomic. */
+__global__ void __launch_bounds__(256) k_shadow_direct(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
+                                                       const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S, uint32_t* cnt) {
+    extern __shared__ __align__(16) int s_stack[];
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    const bool active = idx < total;
+    uint32_t key = 0xFFFFFFFFu;
+    bool occ = false;
+    if (active) {
+        F3 o, d; float lightDistance;
+        shadow_ray_of(sc, fr, drec, dcode, idx, S, key, o, d, lightDistance);
+        Ray r;
+        r.o = o; r.d = d; r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                /* AccelerationStruct.cpp:19 */
+        occ = occluded(sc, r, lightDistance, s_stack + threadIdx.x, blockDim.x);
+    }
+    /* consecutive lanes hold consecutive samples: the first lane of every run of equal keys adds the run's count */
+    const int lane = __lane_id();
+    const uint32_t prev = __shfl_up(key, 1);
+    const unsigned long long leaders = __ballot(active && (lane == 0 || prev != key));
+    const unsigned long long occs = __ballot(occ);
+    if (active && (lane == 0 || prev != key)) {
+        const unsigned long long after = lane == 63 ? 0ull : leaders & (~0ull << (lane + 1));
+        const int stop = after ? __builtin_ctzll(after) : 64;
+        const unsigned long long run = (stop == 64 ? ~0ull : ((1ull << stop) - 1ull)) & (~0ull << lane);
+        const uint32_t n = (uint32_t)__popcll(occs & run);
+        if (n) atomicAdd(cnt + key, n);
+    }
 }
 
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase

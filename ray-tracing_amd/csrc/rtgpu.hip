@@ -274,11 +274,28 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         /* 3. shadow + Phong for the diffuse records of this batch */
         if (n_diff && L > 0) {
             HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
-            /* the records are processed in chunks so that the 32-byte ray buffer stays below ~2 GiB */
             const unsigned long long per_rec = (unsigned long long)L * S;
+            /* no meshes: one thread per ray from record to verdict (k_shadow_direct), no ray buffer, no persistent kernel */
+            const bool direct = c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW");
+            if (direct) {
+                const uint32_t dchunk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(n_diff, (1ull << 38) / per_rec));
+                for (uint32_t r0 = 0; r0 < n_diff; r0 += dchunk) {
+                    const uint32_t nr = std::min(dchunk, n_diff - r0);
+                    const unsigned long long threads = (unsigned long long)nr * per_rec;
+                    EventPair* e2 = next_event(c, 1);
+                    if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+                    HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                    hipLaunchKernelGGL(k_shadow_direct, dim3((uint32_t)((threads + 255) / 256)), dim3(256), (size_t)c->sc.stack_cap * 256 * sizeof(int), c->stream,
+                                       c->sc, c->fr, static_cast<const DiffuseRec*>(c->drec.p) + r0, static_cast<const unsigned long long*>(c->dcode.p) + r0, nr, S,
+                                       static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L);
+                    HIP_TRY(c, hipEventRecord(e2->b, c->stream));
+                    c->stats.rays_shadow += threads;
+                }
+            }
+            /* the records are processed in chunks so that the 32-byte ray buffer stays below ~2 GiB */
             const uint32_t chunk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(n_diff, (64ull << 20) / per_rec));
-            if ((rc = ensure(c, c->srays, (size_t)chunk * per_rec * 2 * sizeof(float4)))) return rc;
-            for (uint32_t r0 = 0; r0 < n_diff; r0 += chunk) {
+            if (!direct && (rc = ensure(c, c->srays, (size_t)chunk * per_rec * 2 * sizeof(float4)))) return rc;
+            for (uint32_t r0 = 0; r0 < n_diff && !direct; r0 += chunk) {
                 const uint32_t nr = std::min(chunk, n_diff - r0);
                 const unsigned long long threads = (unsigned long long)nr * per_rec;
                 /* persistent waves: enough 64-lane blocks to fill the chip, never more than the work */

@@ -379,6 +379,26 @@ def test_random_scenes(rt, ctx, seed):
         radiance_check(g, o, f"random scene {seed} mode {shadow_mode}")
 
 
+@pytest.mark.parametrize("name", ["refraction", "reflexion"])
+def test_direct_shadow_kernel_equals_the_persistent_one(rt, ctx, monkeypatch, name):
+    """Scenes without meshes take k_shadow_direct (one thread per shadow ray, no ray buffer); the persistent kernel gives
+    the same frame, ray counts included."""
+    hs, os_ = scene_pair(rt, ctx, name)
+    assert hs.desc.contents.n_meshes == 0
+    cam = rt.default_camera(1.0)
+    for shadow_mode in (0, 1):
+        p = rt.make_params(96, 96, spp=3, max_depth=6, seed=5, shadow_mode=shadow_mode)
+        direct, dprim, dst = ctx.render(cam, p)
+        monkeypatch.setenv("RT_NO_DIRECT_SHADOW", "1")
+        try:
+            persistent, pprim, pst = ctx.render(cam, p)
+        finally:
+            monkeypatch.delenv("RT_NO_DIRECT_SHADOW")
+        assert np.array_equal(bits(direct), bits(persistent)) and np.array_equal(dprim, pprim)
+        assert (dst.rays_primary, dst.rays_secondary, dst.rays_shadow) == (pst.rays_primary, pst.rays_secondary, pst.rays_shadow)
+        assert dst.rays_shadow > 0
+
+
 @pytest.mark.parametrize("mesh_depth", [2, 14])
 def test_sliver_clouds_and_distance_pruning(rt, ctx, mesh_depth):
     """Needle triangles (height / length from 1e-3 down to 1e-8, any orientation, away from the origin): their stored
