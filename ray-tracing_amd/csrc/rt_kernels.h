@@ -40,7 +40,8 @@ struct Counters {
     uint32_t pad[2];
     unsigned long long rays_primary, rays_secondary, rays_shadow, nonfinite;
     unsigned long long work;        /* next unclaimed shadow-ray index of the running k_shadow launch */
-    unsigned long long pad2;
+    unsigned long long deferred;    /* rays k_shadow_front handed to the running k_shadow launch */
+    unsigned long long deferred_sum; /* ... to all launches of this frame */
     unsigned long long sh_node_steps, sh_tri_steps, sh_other_steps, sh_loop_iters;   /* RT_COUNT=1 diagnostics */
     unsigned long long sh_node_iters, sh_tri_iters, sh_top_iters, sh_top_lanes;
     unsigned long long sh_clk_refill, sh_clk_top, sh_clk_node, sh_clk_tri;             /* wave clocks per section (s_memtime) */      /* wave iterations per phase; lanes entering the top-level step */
@@ -335,7 +336,11 @@ RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
  * mode 1: for the first `limit` leaves, is any object hit at all (any t)? Such a leaf returns an
  *         existing result beyond the light and hides the occluder behind it
  *         (AccelerationStruct.cpp:327-330). Returns 1 / 0. */
-RT_DEV int shadow_walk(const DScene& sc, const Ray& r, float lightDistance, int mode, int limit, int* stk, int stride) {
+/* FRONT (k_shadow_front): meshes are not walked. A mesh whose plane frame the ray misses cannot be hit (every box of
+ * its shadow tree, hence every leaf the reference can reach, lies inside; needs DScene::quant_ok); one that it may hit
+ * sets *defer and ends the walk with -2: that ray goes to the persistent kernel as a whole. */
+template <bool FRONT>
+RT_DEV int shadow_walk(const DScene& sc, const Ray& r, float lightDistance, int mode, int limit, int* stk, int stride, bool* defer = nullptr) {
     const float bound = mode == 0 ? lightDistance : 3.4028233e38f;   /* largest float below FLT_MAX: t < FLT_MAX */
     int visited = 0;
     int sp = 0;
@@ -367,7 +372,16 @@ RT_DEV int shadow_walk(const DScene& sc, const Ray& r, float lightDistance, int 
                     hit = sphere_test(r, q[0], t, n) && t <= bound;
                 } else {
                     DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
-                    hit = mesh_any(sc, m, r, bound, mode == 0, stk, stride, sc.top_cap);
+                    if (FRONT) {
+                        hit = false;
+                        bool may = m.wroot != LINK_NONE;
+                        if (m.wroot >= 0) {
+                            QuantRay qr;
+                            quant_setup(qr, r, m);
+                            quant_entry(0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, qr, 100.0f, may);
+                        }
+                        if (may) { *defer = true; return -2; }
+                    } else hit = mesh_any(sc, m, r, bound, mode == 0, stk, stride, sc.top_cap);
                 }
                 if (hit) return mode == 0 ? visited : 1;
             }
@@ -380,10 +394,18 @@ RT_DEV int shadow_walk(const DScene& sc, const Ray& r, float lightDistance, int 
 }
 
 RT_DEV bool occluded(const DScene& sc, const Ray& r, float lightDistance, int* stk, int stride) {
-    int before = shadow_walk(sc, r, lightDistance, 0, 0, stk, stride);
+    int before = shadow_walk<false>(sc, r, lightDistance, 0, 0, stk, stride);
     if (before < 0) return false;
     if (before == 0) return true;
-    return shadow_walk(sc, r, lightDistance, 1, before, stk, stride) == 0;
+    return shadow_walk<false>(sc, r, lightDistance, 1, before, stk, stride) == 0;
+}
+/* the same for a ray that stays clear of every mesh; otherwise defer is set and the result means nothing */
+RT_DEV bool occluded_front(const DScene& sc, const Ray& r, float lightDistance, int* stk, int stride, bool& defer) {
+    defer = false;
+    int before = shadow_walk<true>(sc, r, lightDistance, 0, 0, stk, stride, &defer);
+    if (defer || before < 0) return false;
+    if (before == 0) return true;
+    return shadow_walk<true>(sc, r, lightDistance, 1, before, stk, stride, &defer) == 0;
 }
 
 /* Scene::isInShadow, Scene.h:160-168 */
@@ -1074,7 +1096,7 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
     uint32_t key; F3 o, d; float lightDistance;
     shadow_ray_of(sc, fr, drec, dcode, idx, S, key, o, d, lightDistance);
     rays[2 * idx] = make_float4(o.x, o.y, o.z, lightDistance);
-    rays[2 * idx + 1] = make_float4(d.x, d.y, d.z, 0.f);
+    rays[2 * idx + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(key));
 }
 
 /* Scenes without meshes (the refraction and reflexion scenes: a sphere and a wall): a shadow ray is a handful of object
@@ -1111,13 +1133,72 @@ __global__ void __launch_bounds__(256) k_shadow_direct(DScene sc, FrameD fr, con
     }
 }
 
+/* Scenes with meshes that most shadow rays pass by (a gorilla on a floor): the front pass settles every ray that stays
+ * clear of all mesh frames the way k_shadow_direct does -- one thread per ray, full occupancy -- and hands the others, as
+ * whole rays, to the persistent kernel through a compact ray buffer (one append atomic per 1024-thread block; *n_deferred
+ * is the persistent kernel's ray count). LDS: top_cap stack entries per thread + 2 * waves + 2 words. */
+#define RT_FBLOCK 1024
+__global__ void __launch_bounds__(RT_FBLOCK) k_shadow_front(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
+                                                            const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S, uint32_t* cnt,
+                                                            float4* __restrict__ rays, unsigned long long* n_deferred, unsigned long long* n_deferred_sum) {
+    extern __shared__ __align__(16) int s_stack[];
+    uint32_t* s_tot = reinterpret_cast<uint32_t*>(s_stack + (size_t)sc.top_cap * blockDim.x);
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    const bool active = idx < total;
+    uint32_t key = 0xFFFFFFFFu;
+    bool occ = false, defer = false;
+    F3 o = f3s(0.f), d = f3s(0.f);
+    float lightDistance = 0.f;
+    if (active) {
+        shadow_ray_of(sc, fr, drec, dcode, idx, S, key, o, d, lightDistance);
+        Ray r;
+        r.o = o; r.d = d; r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                /* AccelerationStruct.cpp:19 */
+        occ = occluded_front(sc, r, lightDistance, s_stack + threadIdx.x, blockDim.x, defer);
+        occ = occ && !defer;
+    }
+    const int lane = __lane_id();
+    {   /* occluded samples: one atomic per run of lanes with the same (record, light) */
+        const uint32_t prev = __shfl_up(key, 1);
+        const bool leader = active && (lane == 0 || prev != key);
+        const unsigned long long leaders = __ballot(leader), occs = __ballot(occ);
+        if (leader) {
+            const unsigned long long after = lane == 63 ? 0ull : leaders & (~0ull << (lane + 1));
+            const int stop = after ? __builtin_ctzll(after) : 64;
+            const unsigned long long run = (stop == 64 ? ~0ull : ((1ull << stop) - 1ull)) & (~0ull << lane);
+            const uint32_t n = (uint32_t)__popcll(occs & run);
+            if (n) atomicAdd(cnt + key, n);
+        }
+    }
+    /* deferred rays: block-aggregated append */
+    const unsigned long long dm = __ballot(defer);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+    if (lane == 0) s_tot[wave] = (uint32_t)__popcll(dm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (int w = 0; w < nwaves; w++) { uint32_t a = s_tot[w]; s_tot[w] = sum; sum += a; }
+        unsigned long long base = 0ull;
+        if (sum) { base = atomicAdd(n_deferred, (unsigned long long)sum); atomicAdd(n_deferred_sum, (unsigned long long)sum); }
+        s_tot[nwaves] = (uint32_t)base; s_tot[nwaves + 1] = (uint32_t)(base >> 32);
+    }
+    __syncthreads();
+    if (defer) {
+        const unsigned long long at = ((unsigned long long)s_tot[nwaves] | ((unsigned long long)s_tot[nwaves + 1] << 32)) + s_tot[wave] + (uint32_t)__popcll(dm & lt);
+        rays[2 * at] = make_float4(o.x, o.y, o.z, lightDistance);
+        rays[2 * at + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(key));
+    }
+}
+
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
 template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves and batched top-level rounds. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
                                                         uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds,
-                                                        int* ovf, int lds_cap, int ovf_cap, int top_min) {
+                                                        int* ovf, int lds_cap, int ovf_cap, int top_min, const unsigned long long* total_ptr) {
     constexpr bool count_steps = COUNT;
+    if (total_ptr) total = *total_ptr;       /* the rays the front pass deferred (k_shadow_front) */
     constexpr bool QUANT = MODE != 0, SUB = MODE == 2;
     extern __shared__ __align__(16) int s_stack[];
     unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0, c_wn = 0, c_wt = 0, c_wtop = 0, c_ltop = 0;
@@ -1180,8 +1261,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const unsigned long long got = __builtin_amdgcn_ballot_w64(s.st == ST_IDLE && idx < total);
             if (lane == 0) traced += __popcll(got);
             if (s.st == ST_IDLE && idx < total) {
-                s.key = (uint32_t)(idx / (unsigned)S);
                 float4 ro = rays[2 * idx], rd = rays[2 * idx + 1];
+                s.key = __float_as_uint(rd.w);
                 s.bound = ro.w;                                                       /* lightDistance */
                 s.r.o = f3(ro.x, ro.y, ro.z);
                 s.r.d = f3(rd.x, rd.y, rd.z);

@@ -31,6 +31,11 @@
 #include <vector>
 #include <utility>
 
+#ifndef RT_FRONT_MAX_SHARE
+#define RT_FRONT_MAX_SHARE 0.35    /* the front pass of the shadow rays stays on if it defers less than this share of them (measured: cow 13 % deferred,
+                                    * frame -13 %; gorilla 27 %, -6 %; default scene 59 %, +22 %; chamber 61 %, +3 %; C5 100 %) */
+#endif
+
 namespace {
 
 struct DevBuf {
@@ -60,6 +65,7 @@ struct rt_ctx {
     uint32_t batch = 1u << 20;
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
+    int front_state = -1;       /* the front pass of the shadow rays (k_shadow_front): -1 = to be probed on this scene, 0 = off, 1 = on */
     size_t stack_cap = 0;       /* states */
     Counters* h_ctr = nullptr;  /* pinned */
     rt_stats stats{};
@@ -220,6 +226,7 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
     Counters* d_ctr = static_cast<Counters*>(c->ctr.p);
     size_t top = 0;
     unsigned long long done = 0;
+    unsigned long long front_rays = 0;      /* shadow rays that went through k_shadow_front in this call */
     size_t lds = lds_bytes(c, RT_BLOCK);
     c->ev_used = 0;
     /* threads per block of k_closest (one append atomic per block): big blocks where rays are cheap and the appends would
@@ -263,8 +270,20 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         else { if (cblock == 64u) launch_closest(k_closest<false, 64>); else launch_closest(k_closest<false, RT_CBLOCK>); }
         HIP_TRY(c, hipEventRecord(e1->b, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
+        if (c->front_state < 0 && front_rays) HIP_TRY(c, hipMemcpyAsync(&c->h_ctr->deferred_sum, &d_ctr->deferred_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
+        if (c->front_state < 0 && front_rays >= (16ull << 20)) {
+            /* the share of deferred rays so far decides for the scene once enough of the frame has been seen (the first
+             * tiles of an image are not the scene); until then the front pass runs */
+            const unsigned long long deferred = c->h_ctr->deferred_sum;
+            const bool enough = front_rays >= (1ull << 30) || done >= src.total;
+            if ((double)deferred > RT_FRONT_MAX_SHARE * (double)front_rays) c->front_state = 0;
+            else if (enough) c->front_state = 1;
+            if (c->debug && c->front_state >= 0)
+                fprintf(stderr, "[rtgpu] front pass: %llu of %llu shadow rays deferred to the persistent kernel -> %s for this scene\n", deferred, front_rays,
+                        c->front_state ? "on" : "off");
+        }
         uint32_t n_child = c->h_ctr->n_child, n_diff = c->h_ctr->n_diffuse;
         c->stats.rays_primary += n_new;                 /* the fresh primaries sit on top of the stack: all of them are in this batch */
         c->stats.rays_secondary += nb - n_new;
@@ -300,14 +319,35 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 const unsigned long long threads = (unsigned long long)nr * per_rec;
                 /* persistent waves: enough 64-lane blocks to fill the chip, never more than the work */
                 const unsigned long long blocks = std::min<unsigned long long>((threads + RT_BLOCK - 1) / RT_BLOCK, (unsigned long long)c->persistent_blocks);
+                unsigned long long blocks_now = blocks;
                 HIP_TRY(c, hipMemsetAsync(&d_ctr->work, 0, sizeof(unsigned long long), c->stream));
-                hipLaunchKernelGGL(k_shadow_setup, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->sc, c->fr,
-                                   static_cast<const DiffuseRec*>(c->drec.p) + r0, static_cast<const unsigned long long*>(c->dcode.p) + r0, nr, S,
-                                   static_cast<float4*>(c->srays.p));
-                EventPair* e2 = next_event(c, 1);
-                if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
-                HIP_TRY(c, hipEventRecord(e2->a, c->stream));
                 uint32_t* cnt0 = static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L;
+                c->stats.rays_shadow += threads;
+                /* Front pass: rays that stay clear of every mesh frame are settled one thread per ray, the rest go to the
+                 * persistent kernel. Whether that pays is the scene's matter (a gorilla on a floor: most rays pass it by;
+                 * C5's soup fills the scene: every ray enters it), so the first launch on a scene looks at the share of
+                 * deferred rays and decides for the scene. */
+                const bool front = c->sc.quant_ok && c->front_state != 0;
+                EventPair* e2 = nullptr;
+                if (front) {
+                    HIP_TRY(c, hipMemsetAsync(&d_ctr->deferred, 0, sizeof(unsigned long long), c->stream));
+                    e2 = next_event(c, 1);
+                    if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+                    HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                    hipLaunchKernelGGL(k_shadow_front, dim3((uint32_t)((threads + RT_FBLOCK - 1) / RT_FBLOCK)), dim3(RT_FBLOCK),
+                                       (size_t)c->sc.top_cap * RT_FBLOCK * sizeof(int) + (RT_FBLOCK / 64 + 2) * sizeof(uint32_t), c->stream, c->sc, c->fr,
+                                       static_cast<const DiffuseRec*>(c->drec.p) + r0, static_cast<const unsigned long long*>(c->dcode.p) + r0, nr, S, cnt0,
+                                       static_cast<float4*>(c->srays.p), &d_ctr->deferred, &d_ctr->deferred_sum);
+                    blocks_now = (unsigned long long)c->persistent_blocks;      /* (how many rays come through is on the device) */
+                    front_rays += threads;
+                } else {
+                    hipLaunchKernelGGL(k_shadow_setup, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->sc, c->fr,
+                                       static_cast<const DiffuseRec*>(c->drec.p) + r0, static_cast<const unsigned long long*>(c->dcode.p) + r0, nr, S,
+                                       static_cast<float4*>(c->srays.p));
+                    e2 = next_event(c, 1);
+                    if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+                    HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                }
                 /* small top-level tables (a few objects) are copied into LDS behind the stacks: a new ray walks them
                  * through four dependent loads while the other lanes of its wave wait */
                 /* (room: 16 blocks per CU share 160 KB of LDS, so stacks + tables may take 10 KB per block) */
@@ -319,13 +359,14 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 if (const char* e = getenv("RT_WIDE_LDS_CAP"))          /* test knob: force the spilling path */
                     if (c->sc.quant_ok && atoi(e) > 0) lds_cap = std::max(c->sc.top_cap + 1, std::min(lds_cap, atoi(e)));
                 const int ovf_cap = c->sc.quant_ok ? std::max(0, c->sc.wstack_cap - lds_cap) : 0;
-                if ((rc = ensure(c, c->ovf, std::max<size_t>(256, (size_t)blocks * ovf_cap * RT_BLOCK * sizeof(int))))) return rc;
+                if ((rc = ensure(c, c->ovf, std::max<size_t>(256, (size_t)std::max<unsigned long long>(blocks, blocks_now) * ovf_cap * RT_BLOCK * sizeof(int))))) return rc;
                 int top_min = c->sc.n_top_items >= 24 ? 32 : 1;       /* see k_shadow; measured on the default scene: 1, 8, 16, 32, 48, 60 -> 2365, 2205, 2065, 1828, 1839, 2111 ms */
                 if (const char* e = getenv("RT_TOP_MIN")) top_min = std::max(1, atoi(e));
                 auto launch = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, c->sc,
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks_now), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, c->sc,
                                        static_cast<const float4*>(c->srays.p), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds,
-                                       static_cast<int*>(c->ovf.p), lds_cap, ovf_cap, top_min);
+                                       static_cast<int*>(c->ovf.p), lds_cap, ovf_cap, top_min,
+                                       front ? static_cast<const unsigned long long*>(&d_ctr->deferred) : static_cast<const unsigned long long*>(nullptr));
                 };
                 if (c->sc.quant_ok && (c->sc.has_sub || top_min > 1)) { if (c->count_steps) launch(k_shadow<2, true>); else launch(k_shadow<2, false>); }
                 else if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<1, true>); else launch(k_shadow<1, false>); }
@@ -350,7 +391,6 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    c->stats.rays_shadow += c->h_ctr->rays_shadow;
     c->stats.nonfinite += c->h_ctr->nonfinite;
     if (c->count_steps)
         fprintf(stderr, "[rtgpu] shadow steps: node %llu tri %llu other %llu lane-iterations %llu rays %llu; wave iterations: node %llu tri %llu top %llu (top lanes %llu)\n",
@@ -1207,6 +1247,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     if (c->debug) fprintf(stderr, "[rtgpu] scene: %lld mesh nodes, depth %d, quantised shadow nodes %s\n", (long long)d->n_mesh_nodes, max_mesh_depth,
                           sc.quant_ok ? "on" : "off");
     c->sc = sc;
+    c->front_state = -1;
+    if (const char* e = getenv("RT_FRONT")) c->front_state = atoi(e) ? 1 : 0;     /* test knob: 1 = always, 0 = never */
     c->n_lights = d->n_lights;
     c->has_scene = true;
     return RT_OK;
