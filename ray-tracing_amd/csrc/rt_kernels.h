@@ -454,21 +454,6 @@ RT_DEV void accumulate(long long* acc, uint32_t* nonfinite, Counters* ctr, uint3
     }
 }
 
-/* wave-aggregated append: every lane of the wave calls this with its own request count */
-RT_DEV uint32_t wave_reserve(uint32_t* counter, uint32_t want) {
-    unsigned long long m1 = __ballot(want == 1), m2 = __ballot(want == 2);
-    int lane = __lane_id();
-    unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t mine = __popcll(m1 & lt) + 2u * __popcll(m2 & lt);
-    uint32_t total = __popcll(m1) + 2u * __popcll(m2);
-    uint32_t base = 0;
-    if (total) {
-        if (lane == 0) base = atomicAdd(counter, total);
-        base = __shfl(base, 0);
-    }
-    return base + mine;
-}
-
 /* Block-aggregated append to the two queues of k_closest at once: every thread of the block calls this (no early
  * exits before it) with its own request counts. All waves of all blocks used to hit the same two counters with
  * returning atomics (plus two for the ray statistics): on scenes with cheap rays that contention, not the
