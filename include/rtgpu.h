@@ -197,6 +197,17 @@ int rt_occluded(rt_ctx*, const float* pts, const float* light_pos, int64_t n, in
 /* Scene::rayTrace (Scene.h:283-286) on n rays; pixel/sample key the light-sampling RNG. */
 int rt_trace(rt_ctx*, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample,
              int64_t n, const rt_render_params*, float* rgb);
+/* rt_trace for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc). No counterpart in the reference. Same arguments, same radiance bits as rt_trace, but it calls no hipMalloc /
+ * hipFree / hipEventCreate: staging, path states, queues, counters, shadow rays and the spill slices of the shadow walk
+ * live in a file-scope __device__ array of RT_STATIC_BYTES = 8 MiB that every GPU the library runs on holds until the
+ * process ends (address taken once per context, in rt_init). Limits (RT_ERR_LIMIT beyond them): n <= RT_STATIC_MAX_RAYS,
+ * max_depth <= RT_STATIC_MAX_DEPTH, lights x light_samples <= 65536, and a scene whose 4-wide shadow walk spills at
+ * most 64 stack entries per lane. All calls on one GPU share the array: calls that overlap on one GPU race. */
+#define RT_STATIC_MAX_RAYS 4096
+#define RT_STATIC_MAX_DEPTH 8
+int rt_trace_static(rt_ctx*, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample,
+                    int64_t n, const rt_render_params*, float* rgb);
 /* Primary rays of a tile exactly as the render kernels generate them (w*h*spp, sample-minor). */
 int rt_camera_rays(rt_ctx*, const rt_render_params*, int x0, int y0, int w, int h, float* org, float* dir);
 

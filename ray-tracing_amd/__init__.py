@@ -110,7 +110,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
 # every symbol include/rtgpu.h and include/rthost.h declare
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame",
            "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_get_stats",
-           "rt_intersect", "rt_occluded", "rt_trace", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion",
+           "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
            "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_scene_desc",
            "rth_ray_trace_from_camera", "rth_write_ppm", "rth_load_off", "rth_scene_save", "rth_scene_load"]
@@ -151,6 +151,7 @@ def lib():
     L.rt_intersect.argtypes = [vp, vp, vp, i64, vp]
     L.rt_occluded.argtypes = [vp, vp, vp, i64, vp]
     L.rt_trace.argtypes = [vp, vp, vp, vp, vp, i64, C.POINTER(RenderParams), vp]
+    L.rt_trace_static.argtypes = [vp, vp, vp, vp, vp, i64, C.POINTER(RenderParams), vp]
     L.rt_camera_rays.argtypes = [vp, C.POINTER(RenderParams), i32, i32, i32, i32, vp, vp]
     L.rt_rng.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     L.rt_rng.restype = C.c_uint32
@@ -427,15 +428,17 @@ class Context:
         self._check(self.L.rt_occluded(self.h, _ptr(pts), _ptr(lights), len(pts), _ptr(out)), "rt_occluded")
         return out
 
-    def trace(self, org, dirs, params, pixel=None, sample=None):
+    def trace(self, org, dirs, params, pixel=None, sample=None, static=False):
+        """Scene::rayTrace on explicit rays; static=True goes through rt_trace_static (no allocation, small inputs)."""
         org = np.ascontiguousarray(org, np.float32)
         dirs = np.ascontiguousarray(dirs, np.float32)
         n = len(org)
         pixel = np.arange(n, dtype=np.uint32) if pixel is None else np.ascontiguousarray(pixel, np.uint32)
         sample = np.zeros(n, np.uint32) if sample is None else np.ascontiguousarray(sample, np.uint32)
         rgb = np.zeros((n, 3), np.float32)
-        self._check(self.L.rt_trace(self.h, _ptr(org), _ptr(dirs), _ptr(pixel), _ptr(sample), n, C.byref(params), _ptr(rgb)),
-                    "rt_trace")
+        fn = self.L.rt_trace_static if static else self.L.rt_trace
+        self._check(fn(self.h, _ptr(org), _ptr(dirs), _ptr(pixel), _ptr(sample), n, C.byref(params), _ptr(rgb)),
+                    "rt_trace_static" if static else "rt_trace")
         return rgb
 
     def camera_rays(self, params, x0, y0, w, h):

@@ -47,6 +47,12 @@ struct EventPair { hipEvent_t a, b; int kind; };
 
 }  // namespace
 
+/* Scratch memory of rt_trace_static, the entry point that allocates nothing (include/rtgpu.h): every device the
+ * library runs on holds its own copy of this array until the process ends. In host code the name is a stand-in,
+ * not an address: rt_init asks hipGetSymbolAddress for this device's copy and only that pointer is ever used. */
+#define RT_STATIC_BYTES (8u << 20)
+static __device__ __align__(256) unsigned char rt_static_scratch[RT_STATIC_BYTES];
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -66,12 +72,12 @@ struct rt_ctx {
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
     int front_state = -1;       /* the front pass of the shadow rays (k_shadow_front): -1 = to be probed on this scene, 0 = off, 1 = on */
-    size_t stack_cap = 0;       /* states */
     Counters* h_ctr = nullptr;  /* pinned */
     rt_stats stats{};
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
     hipEvent_t ev_frame_a = nullptr, ev_frame_b = nullptr;
+    unsigned char* static_scratch = nullptr;   /* this device's copy of rt_static_scratch (rt_trace_static) */
 };
 
 namespace {
@@ -197,33 +203,81 @@ struct Source {                 /* where fresh path states come from */
     int max_depth;
 };
 
-/* The wavefront loop. Path states sit on a LIFO stack; every iteration tops the batch up with
- * fresh primaries, pops up to `batch` states (deepest first, which bounds the live set by
- * batch*(max_depth+2)), runs closest-hit + material dispatch, the shadow pass and the Phong
- * pass for that batch, then pushes the children. */
-int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
+/* Device memory one run of the wavefront loop works in: the library's own growing buffers (bufs_from_ctx) or a
+ * carve-up of the static scratch array (rt_trace_static, which must not allocate). */
+struct WaveBufs {
+    PathState* stack; size_t stack_cap;     /* LIFO of path states */
+    PathState* child;                       /* 2 * batch */
+    DiffuseRec* drec; unsigned long long* dcode; uint32_t* dtex;   /* batch each */
+    uint32_t* cnt;                          /* batch * lights */
+    Counters* ctr;
+    TileD* tilebuf;                         /* from_tiles only */
+    float4* srays; unsigned long long srays_cap;    /* shadow-ray buffer, capacity in rays (2 float4 each) */
+    int* ovf; size_t ovf_bytes;             /* spill slices of the 4-wide shadow walk */
+    uint32_t batch;
+    int persistent_blocks;
+    bool timing;                            /* record HIP events per launch (creates events on demand) */
+};
+
+int wide_ovf_cap(const rt_ctx* c, int* lds_cap_out) {
+    /* stack entries of a lane kept in LDS (the first stack_cap = what the binary walks need; the 4-wide shadow walk
+     * can need three per level and spills the rest -- rare -- to a global slice) */
+    int lds_cap = c->sc.stack_cap;
+    if (const char* e = getenv("RT_WIDE_LDS_CAP"))          /* test knob: force the spilling path */
+        if (c->sc.quant_ok && atoi(e) > 0) lds_cap = std::max(c->sc.top_cap + 1, std::min(lds_cap, atoi(e)));
+    if (lds_cap_out) *lds_cap_out = lds_cap;
+    return c->sc.quant_ok ? std::max(0, c->sc.wstack_cap - lds_cap) : 0;
+}
+
+/* the library's own buffers, grown to what this run can need */
+int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
     const uint32_t B = c->batch;
     const int L = c->n_lights;
     const int S = c->fr.shadow_mode == 1 ? 1 : c->fr.light_samples;
     size_t need_stack = (size_t)B * (size_t)(src.max_depth + 3);
     int rc;
     if ((rc = ensure(c, c->stack, need_stack * sizeof(PathState)))) return rc;
-    c->stack_cap = c->stack.bytes / sizeof(PathState);
     if ((rc = ensure(c, c->child, (size_t)2 * B * sizeof(PathState)))) return rc;
     if ((rc = ensure(c, c->drec, (size_t)B * sizeof(DiffuseRec)))) return rc;
     if ((rc = ensure(c, c->dcode, (size_t)B * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(c, c->dtex, (size_t)B * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->cnt, (size_t)B * std::max(L, 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->ctr, sizeof(Counters)))) return rc;
-    if (!c->h_ctr) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
-    if (src.from_tiles) {
-        if ((rc = ensure(c, c->tilebuf, std::max<size_t>(c->tiles.size(), 1) * sizeof(TileD)))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->tilebuf.p, c->tiles.data(), c->tiles.size() * sizeof(TileD), hipMemcpyHostToDevice, c->stream));
-    }
-    HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(Counters), c->stream));
+    if (src.from_tiles && (rc = ensure(c, c->tilebuf, std::max<size_t>(c->tiles.size(), 1) * sizeof(TileD)))) return rc;
+    /* the records of a batch are processed in chunks so that the 32-byte ray buffer stays below ~2 GiB */
+    const unsigned long long per_rec = (unsigned long long)std::max(L, 1) * S;
+    const unsigned long long chunk = std::max<unsigned long long>(1ull, std::min<unsigned long long>(B, (64ull << 20) / per_rec));
+    const bool direct = c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW");
+    if (!direct && L > 0 && (rc = ensure(c, c->srays, (size_t)(chunk * per_rec) * 2 * sizeof(float4)))) return rc;
+    const int ovf_cap = wide_ovf_cap(c, nullptr);
+    if ((rc = ensure(c, c->ovf, std::max<size_t>(256, (size_t)c->persistent_blocks * ovf_cap * RT_BLOCK * sizeof(int))))) return rc;
+    w.stack = static_cast<PathState*>(c->stack.p); w.stack_cap = c->stack.bytes / sizeof(PathState);
+    w.child = static_cast<PathState*>(c->child.p);
+    w.drec = static_cast<DiffuseRec*>(c->drec.p); w.dcode = static_cast<unsigned long long*>(c->dcode.p); w.dtex = static_cast<uint32_t*>(c->dtex.p);
+    w.cnt = static_cast<uint32_t*>(c->cnt.p); w.ctr = static_cast<Counters*>(c->ctr.p);
+    w.tilebuf = static_cast<TileD*>(c->tilebuf.p);
+    w.srays = static_cast<float4*>(c->srays.p); w.srays_cap = c->srays.bytes / (2 * sizeof(float4));
+    w.ovf = static_cast<int*>(c->ovf.p); w.ovf_bytes = c->ovf.bytes;
+    w.batch = B; w.persistent_blocks = c->persistent_blocks; w.timing = true;
+    return RT_OK;
+}
 
-    PathState* stack = static_cast<PathState*>(c->stack.p);
-    Counters* d_ctr = static_cast<Counters*>(c->ctr.p);
+/* The wavefront loop. Path states sit on a LIFO stack; every iteration tops the batch up with
+ * fresh primaries, pops up to `batch` states (deepest first, which bounds the live set by
+ * batch*(max_depth+2)), runs closest-hit + material dispatch, the shadow pass and the Phong
+ * pass for that batch, then pushes the children. Allocates nothing itself: all device memory comes in through `w`
+ * (and no events are created when w.timing is off). */
+int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* acc, uint32_t* nonfinite, uint32_t* prim) {
+    const uint32_t B = w.batch;
+    const int L = c->n_lights;
+    const int S = c->fr.shadow_mode == 1 ? 1 : c->fr.light_samples;
+    if (w.stack_cap < (size_t)B * (size_t)(src.max_depth + 3)) return fail(c, RT_ERR_LIMIT, "path-state stack too small for depth %d", src.max_depth);
+    if (src.from_tiles)
+        HIP_TRY(c, hipMemcpyAsync(w.tilebuf, c->tiles.data(), c->tiles.size() * sizeof(TileD), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(w.ctr, 0, sizeof(Counters), c->stream));
+
+    PathState* stack = w.stack;
+    Counters* d_ctr = w.ctr;
     size_t top = 0;
     unsigned long long done = 0;
     unsigned long long front_rays = 0;      /* shadow rays that went through k_shadow_front in this call */
@@ -243,7 +297,7 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         if (n_new) {
             dim3 g((n_new + 255) / 256), b(256);
             if (src.from_tiles)
-                hipLaunchKernelGGL(k_raygen, g, b, 0, c->stream, c->cam, c->fr, static_cast<const TileD*>(c->tilebuf.p), (int)c->tiles.size(),
+                hipLaunchKernelGGL(k_raygen, g, b, 0, c->stream, c->cam, c->fr, static_cast<const TileD*>(w.tilebuf), (int)c->tiles.size(),
                                    done, n_new, stack + top);
             else
                 hipLaunchKernelGGL(k_seed, g, b, 0, c->stream, src.d_org, src.d_dir, src.d_pixel, src.d_sample, (uint32_t)done, n_new,
@@ -255,21 +309,22 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         uint32_t nb = (uint32_t)std::min<size_t>(top, B);
         size_t base = top - nb;
         top = base;
-        HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, 16, c->stream));    /* n_child, n_diffuse */
-        EventPair* e1 = next_event(c, 0);
-        if (!e1) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
-        HIP_TRY(c, hipEventRecord(e1->a, c->stream));
+        HIP_TRY(c, hipMemsetAsync(w.ctr, 0, 16, c->stream));    /* n_child, n_diffuse */
+        EventPair* e1 = nullptr;
+        if (w.timing) {
+            if (!(e1 = next_event(c, 0))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+            HIP_TRY(c, hipEventRecord(e1->a, c->stream));
+        }
         /* (a batch of bounced rays is the heavy, divergent kind: default scene 147 ms with one wave per block, 169 with four) */
         if (!getenv("RT_CBLOCK")) cblock = (2ull * n_new >= nb) ? cblock_light : 64u;
         auto launch_closest = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((nb + cblock - 1) / cblock), dim3(cblock), lds_bytes_closest(c, cblock) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, c->sc, stack + base, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
-                               static_cast<PathState*>(c->child.p), 2 * B, static_cast<DiffuseRec*>(c->drec.p),
-                               static_cast<unsigned long long*>(c->dcode.p), static_cast<uint32_t*>(c->dtex.p), B, d_ctr, acc, nonfinite, prim);
+                               w.child, 2 * B, w.drec, w.dcode, w.dtex, B, d_ctr, acc, nonfinite, prim);
         };
         if (c->sc.has_sub && c->sc.quant_ok) { if (cblock == 64u) launch_closest(k_closest<true, 64>); else launch_closest(k_closest<true, RT_CBLOCK>); }
         else { if (cblock == 64u) launch_closest(k_closest<false, 64>); else launch_closest(k_closest<false, RT_CBLOCK>); }
-        HIP_TRY(c, hipEventRecord(e1->b, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
+        if (e1) HIP_TRY(c, hipEventRecord(e1->b, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_ctr, w.ctr, 16, hipMemcpyDeviceToHost, c->stream));
         if (c->front_state < 0 && front_rays) HIP_TRY(c, hipMemcpyAsync(&c->h_ctr->deferred_sum, &d_ctr->deferred_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
@@ -292,7 +347,7 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
         if (n_child > 2 * B || n_diff > B) return fail(c, RT_ERR_LIMIT, "queue overflow (%u children, %u diffuse)", n_child, n_diff);
         /* 3. shadow + Phong for the diffuse records of this batch */
         if (n_diff && L > 0) {
-            HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(w.cnt, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
             const unsigned long long per_rec = (unsigned long long)L * S;
             /* no meshes: one thread per ray from record to verdict (k_shadow_direct), no ray buffer, no persistent kernel */
             const bool direct = c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW");
@@ -301,27 +356,28 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 for (uint32_t r0 = 0; r0 < n_diff; r0 += dchunk) {
                     const uint32_t nr = std::min(dchunk, n_diff - r0);
                     const unsigned long long threads = (unsigned long long)nr * per_rec;
-                    EventPair* e2 = next_event(c, 1);
-                    if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
-                    HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                    EventPair* e2 = nullptr;
+                    if (w.timing) {
+                        if (!(e2 = next_event(c, 1))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+                        HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                    }
                     hipLaunchKernelGGL(k_shadow_direct, dim3((uint32_t)((threads + 255) / 256)), dim3(256), (size_t)c->sc.stack_cap * 256 * sizeof(int), c->stream,
-                                       c->sc, c->fr, static_cast<const DiffuseRec*>(c->drec.p) + r0, static_cast<const unsigned long long*>(c->dcode.p) + r0, nr, S,
-                                       static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L);
-                    HIP_TRY(c, hipEventRecord(e2->b, c->stream));
+                                       c->sc, c->fr, w.drec + r0, w.dcode + r0, nr, S, w.cnt + (size_t)r0 * L);
+                    if (e2) HIP_TRY(c, hipEventRecord(e2->b, c->stream));
                     c->stats.rays_shadow += threads;
                 }
             }
-            /* the records are processed in chunks so that the 32-byte ray buffer stays below ~2 GiB */
-            const uint32_t chunk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(n_diff, (64ull << 20) / per_rec));
-            if (!direct && (rc = ensure(c, c->srays, (size_t)chunk * per_rec * 2 * sizeof(float4)))) return rc;
+            /* the records are processed in chunks that fit the 32-byte ray buffer */
+            if (!direct && w.srays_cap < per_rec) return fail(c, RT_ERR_LIMIT, "shadow-ray buffer too small for %d lights x %d samples", L, S);
+            const uint32_t chunk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(n_diff, w.srays_cap / per_rec));
             for (uint32_t r0 = 0; r0 < n_diff && !direct; r0 += chunk) {
                 const uint32_t nr = std::min(chunk, n_diff - r0);
                 const unsigned long long threads = (unsigned long long)nr * per_rec;
                 /* persistent waves: enough 64-lane blocks to fill the chip, never more than the work */
-                const unsigned long long blocks = std::min<unsigned long long>((threads + RT_BLOCK - 1) / RT_BLOCK, (unsigned long long)c->persistent_blocks);
+                const unsigned long long blocks = std::min<unsigned long long>((threads + RT_BLOCK - 1) / RT_BLOCK, (unsigned long long)w.persistent_blocks);
                 unsigned long long blocks_now = blocks;
                 HIP_TRY(c, hipMemsetAsync(&d_ctr->work, 0, sizeof(unsigned long long), c->stream));
-                uint32_t* cnt0 = static_cast<uint32_t*>(c->cnt.p) + (size_t)r0 * L;
+                uint32_t* cnt0 = w.cnt + (size_t)r0 * L;
                 c->stats.rays_shadow += threads;
                 /* Front pass: rays that stay clear of every mesh frame are settled one thread per ray, the rest go to the
                  * persistent kernel. Whether that pays is the scene's matter (a gorilla on a floor: most rays pass it by;
@@ -331,64 +387,61 @@ int run_wavefront(rt_ctx* c, const Source& src, long long* acc, uint32_t* nonfin
                 EventPair* e2 = nullptr;
                 if (front) {
                     HIP_TRY(c, hipMemsetAsync(&d_ctr->deferred, 0, sizeof(unsigned long long), c->stream));
-                    e2 = next_event(c, 1);
-                    if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
-                    HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                    if (w.timing) {
+                        if (!(e2 = next_event(c, 1))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+                        HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                    }
                     hipLaunchKernelGGL(k_shadow_front, dim3((uint32_t)((threads + RT_FBLOCK - 1) / RT_FBLOCK)), dim3(RT_FBLOCK),
                                        (size_t)c->sc.top_cap * RT_FBLOCK * sizeof(int) + (RT_FBLOCK / 64 + 2) * sizeof(uint32_t), c->stream, c->sc, c->fr,
-                                       static_cast<const DiffuseRec*>(c->drec.p) + r0, static_cast<const unsigned long long*>(c->dcode.p) + r0, nr, S, cnt0,
-                                       static_cast<float4*>(c->srays.p), &d_ctr->deferred, &d_ctr->deferred_sum);
-                    blocks_now = (unsigned long long)c->persistent_blocks;      /* (how many rays come through is on the device) */
+                                       w.drec + r0, w.dcode + r0, nr, S, cnt0, w.srays, &d_ctr->deferred, &d_ctr->deferred_sum);
+                    blocks_now = (unsigned long long)w.persistent_blocks;      /* (how many rays come through is on the device) */
                     front_rays += threads;
                 } else {
                     hipLaunchKernelGGL(k_shadow_setup, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->sc, c->fr,
-                                       static_cast<const DiffuseRec*>(c->drec.p) + r0, static_cast<const unsigned long long*>(c->dcode.p) + r0, nr, S,
-                                       static_cast<float4*>(c->srays.p));
-                    e2 = next_event(c, 1);
-                    if (!e2) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
-                    HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                                       w.drec + r0, w.dcode + r0, nr, S, w.srays);
+                    if (w.timing) {
+                        if (!(e2 = next_event(c, 1))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
+                        HIP_TRY(c, hipEventRecord(e2->a, c->stream));
+                    }
                 }
                 /* small top-level tables (a few objects) are copied into LDS behind the stacks: a new ray walks them
                  * through four dependent loads while the other lanes of its wave wait */
                 /* (room: 16 blocks per CU share 160 KB of LDS, so stacks + tables may take 10 KB per block) */
                 const size_t top_room = std::max<size_t>(RT_TOP_LDS_MAX, lds < 10240 ? 10240 - lds : 0);
                 const int top_lds = ((size_t)c->sc.top_blob_bytes <= top_room && !getenv("RT_TOP_GLOBAL")) ? 1 : 0;
-                /* stack entries of a lane kept in LDS (the first stack_cap = what the binary walks need; the 4-wide shadow walk
-                 * can need three per level and spills the rest -- rare -- to a global slice) */
-                int lds_cap = c->sc.stack_cap;
-                if (const char* e = getenv("RT_WIDE_LDS_CAP"))          /* test knob: force the spilling path */
-                    if (c->sc.quant_ok && atoi(e) > 0) lds_cap = std::max(c->sc.top_cap + 1, std::min(lds_cap, atoi(e)));
-                const int ovf_cap = c->sc.quant_ok ? std::max(0, c->sc.wstack_cap - lds_cap) : 0;
-                if ((rc = ensure(c, c->ovf, std::max<size_t>(256, (size_t)std::max<unsigned long long>(blocks, blocks_now) * ovf_cap * RT_BLOCK * sizeof(int))))) return rc;
+                int lds_cap = 0;
+                const int ovf_cap = wide_ovf_cap(c, &lds_cap);
+                if ((size_t)std::max<unsigned long long>(blocks, blocks_now) * ovf_cap * RT_BLOCK * sizeof(int) > w.ovf_bytes)
+                    return fail(c, RT_ERR_LIMIT, "spill buffer of the shadow walk too small (%d entries per lane)", ovf_cap);
                 int top_min = c->sc.n_top_items >= 24 ? 32 : 1;       /* see k_shadow; measured on the default scene: 1, 8, 16, 32, 48, 60 -> 2365, 2205, 2065, 1828, 1839, 2111 ms */
                 if (const char* e = getenv("RT_TOP_MIN")) top_min = std::max(1, atoi(e));
                 auto launch = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3((uint32_t)blocks_now), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, c->sc,
-                                       static_cast<const float4*>(c->srays.p), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds,
-                                       static_cast<int*>(c->ovf.p), lds_cap, ovf_cap, top_min,
+                                       static_cast<const float4*>(w.srays), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds,
+                                       w.ovf, lds_cap, ovf_cap, top_min,
                                        front ? static_cast<const unsigned long long*>(&d_ctr->deferred) : static_cast<const unsigned long long*>(nullptr));
                 };
                 if (c->sc.quant_ok && (c->sc.has_sub || top_min > 1)) { if (c->count_steps) launch(k_shadow<2, true>); else launch(k_shadow<2, false>); }
                 else if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<1, true>); else launch(k_shadow<1, false>); }
                 else { if (c->count_steps) launch(k_shadow<0, true>); else launch(k_shadow<0, false>); }
-                HIP_TRY(c, hipEventRecord(e2->b, c->stream));
+                if (e2) HIP_TRY(c, hipEventRecord(e2->b, c->stream));
             }
         }
         if (n_diff) {
-            if (L == 0) HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, 256, c->stream));
-            hipLaunchKernelGGL(k_shade, dim3((n_diff + 255) / 256), dim3(256), 0, c->stream, c->sc, static_cast<const DiffuseRec*>(c->drec.p),
-                               static_cast<const uint32_t*>(c->dtex.p), n_diff, S, static_cast<const uint32_t*>(c->cnt.p), acc, nonfinite, d_ctr);
+            if (L == 0) HIP_TRY(c, hipMemsetAsync(w.cnt, 0, 256, c->stream));
+            hipLaunchKernelGGL(k_shade, dim3((n_diff + 255) / 256), dim3(256), 0, c->stream, c->sc, w.drec,
+                               w.dtex, n_diff, S, w.cnt, acc, nonfinite, d_ctr);
         }
         /* 4. push the children */
         if (n_child) {
-            if (top + n_child > c->stack_cap) return fail(c, RT_ERR_LIMIT, "path-state stack overflow");
-            HIP_TRY(c, hipMemcpyAsync(stack + top, c->child.p, (size_t)n_child * sizeof(PathState), hipMemcpyDeviceToDevice, c->stream));
+            if (top + n_child > w.stack_cap) return fail(c, RT_ERR_LIMIT, "path-state stack overflow");
+            HIP_TRY(c, hipMemcpyAsync(stack + top, w.child, (size_t)n_child * sizeof(PathState), hipMemcpyDeviceToDevice, c->stream));
             top += n_child;
         }
         c->stats.iterations++;
         c->stats.peak_states = std::max<uint64_t>(c->stats.peak_states, top);
     }
-    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, w.ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->stats.nonfinite += c->h_ctr->nonfinite;
@@ -868,6 +921,15 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
         hipEventCreate(&c->ev_frame_b) != hipSuccess) {
         delete c;
         return RT_ERR_DEVICE;
+    }
+    {   /* set-up that must not happen later: the pinned read-back block and this device's address of the static scratch */
+        void* sp = nullptr;
+        if (hipHostMalloc((void**)&c->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess ||
+            hipGetSymbolAddress(&sp, HIP_SYMBOL(rt_static_scratch)) != hipSuccess || !sp) {
+            rt_shutdown(c);
+            return RT_ERR_DEVICE;
+        }
+        c->static_scratch = static_cast<unsigned char*>(sp);
     }
     const char* b = getenv("RT_BATCH");
     if (b && atoi(b) >= 1024) c->batch = (uint32_t)atoi(b);
@@ -1363,8 +1425,11 @@ int rt_flush(rt_ctx* c) {
     src.from_tiles = true;
     src.total = c->queued_samples;
     src.max_depth = c->fr.max_depth;
+    WaveBufs wb{};
+    int rc = bufs_from_ctx(c, src, wb);
+    if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_frame_a, c->stream));
-    int rc = run_wavefront(c, src, static_cast<long long*>(c->acc.p), static_cast<uint32_t*>(c->nf.p), static_cast<uint32_t*>(c->prim.p));
+    rc = run_wavefront(c, src, wb, static_cast<long long*>(c->acc.p), static_cast<uint32_t*>(c->nf.p), static_cast<uint32_t*>(c->prim.p));
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_frame_b, c->stream));
     HIP_TRY(c, hipEventSynchronize(c->ev_frame_b));
@@ -1489,7 +1554,9 @@ int rt_trace(rt_ctx* c, const float* org, const float* dir, const uint32_t* pixe
     src.d_org = static_cast<const float*>(a.p); src.d_dir = static_cast<const float*>(b.p);
     src.d_pixel = static_cast<const uint32_t*>(px.p); src.d_sample = static_cast<const uint32_t*>(sm.p);
     src.max_depth = q.max_depth;
-    rc = run_wavefront(c, src, static_cast<long long*>(acc.p), static_cast<uint32_t*>(nf.p), nullptr);
+    WaveBufs wb{};
+    rc = bufs_from_ctx(c, src, wb);
+    if (rc == RT_OK) rc = run_wavefront(c, src, wb, static_cast<long long*>(acc.p), static_cast<uint32_t*>(nf.p), nullptr);
     if (rc == RT_OK) {
         hipLaunchKernelGGL(k_resolve, dim3(((uint32_t)n * 3 + 255) / 256), dim3(256), 0, c->stream, static_cast<const long long*>(acc.p),
                            static_cast<const uint32_t*>(nf.p), (uint32_t)n, 1, static_cast<float*>(out.p));
@@ -1498,6 +1565,94 @@ int rt_trace(rt_ctx* c, const float* org, const float* dir, const uint32_t* pixe
         if (e != hipSuccess) rc = fail(c, RT_ERR_DEVICE, "rt_trace: %s", hipGetErrorString(e));
     }
     cleanup();
+    return rc;
+}
+
+/* rt_trace without a single allocation: staging, path states, queues, counters, shadow rays and spill slices all live
+ * in this device's copy of rt_static_scratch (address taken once, in rt_init). Same kernels and same host loop as
+ * rt_trace (run_wavefront with a small batch), so the radiance has the same bits: the sums are order-independent fixed
+ * point. Calls on one GPU share the array -- everything that must start at zero is cleared here (accumulators, flags,
+ * counters; the per-batch queues are cleared by the loop) -- and calls that overlap on one GPU would race. */
+int rt_trace_static(rt_ctx* c, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample, int64_t n,
+                    const rt_render_params* p, float* rgb) {
+    if (!c || !org || !dir || !pixel || !sample || !p || !rgb || n < 0) return RT_ERR_ARG;
+    if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
+    if (n > RT_STATIC_MAX_RAYS) return fail(c, RT_ERR_LIMIT, "rt_trace_static: %lld rays, the limit is %d", (long long)n, RT_STATIC_MAX_RAYS);
+    if (p->max_depth > RT_STATIC_MAX_DEPTH) return fail(c, RT_ERR_LIMIT, "rt_trace_static: max_depth %d, the limit is %d", p->max_depth, RT_STATIC_MAX_DEPTH);
+    if (n == 0) return RT_OK;
+    rt_render_params q = *p;
+    if (q.img_w <= 0) q.img_w = 1;
+    if (q.img_h <= 0) q.img_h = 1;
+    q.spp = 1;
+    int rc = check_params(c, &q);
+    if (rc) return rc;
+    if (!c->static_scratch) return fail(c, RT_ERR_STATE, "rt_trace_static: no scratch address (rt_init)");
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    /* carve-up of the scratch array (256-byte aligned pieces) */
+    constexpr uint32_t B = 1024;                    /* batch */
+    constexpr unsigned long long SRAYS = 65536;     /* shadow rays per k_shadow launch */
+    constexpr int BLOCKS = 256;                     /* persistent blocks */
+    const int L = c->n_lights;
+    const int S = q.shadow_mode == 1 ? 1 : q.light_samples;
+    if ((unsigned long long)std::max(L, 1) * S > SRAYS)
+        return fail(c, RT_ERR_LIMIT, "rt_trace_static: %d lights x %d samples, the limit is %llu shadow rays per hit", L, S, SRAYS);
+    const int ovf_cap = wide_ovf_cap(c, nullptr);
+    size_t off = 0;
+    bool fits = true;
+    auto take = [&](size_t bytes) -> unsigned char* {
+        unsigned char* at = c->static_scratch + off;
+        off += (bytes + 255) & ~(size_t)255;
+        if (off > RT_STATIC_BYTES) fits = false;
+        return at;
+    };
+    float* d_org = reinterpret_cast<float*>(take((size_t)n * 12));
+    float* d_dir = reinterpret_cast<float*>(take((size_t)n * 12));
+    uint32_t* d_px = reinterpret_cast<uint32_t*>(take((size_t)n * 4));
+    uint32_t* d_sm = reinterpret_cast<uint32_t*>(take((size_t)n * 4));
+    long long* d_acc = reinterpret_cast<long long*>(take((size_t)n * 3 * sizeof(long long)));
+    uint32_t* d_nf = reinterpret_cast<uint32_t*>(take((size_t)n * 4));
+    float* d_out = reinterpret_cast<float*>(take((size_t)n * 12));
+    WaveBufs w{};
+    w.batch = B; w.persistent_blocks = BLOCKS; w.timing = false;
+    w.stack_cap = (size_t)B * (RT_STATIC_MAX_DEPTH + 3);
+    w.stack = reinterpret_cast<PathState*>(take(w.stack_cap * sizeof(PathState)));
+    w.child = reinterpret_cast<PathState*>(take((size_t)2 * B * sizeof(PathState)));
+    w.drec = reinterpret_cast<DiffuseRec*>(take((size_t)B * sizeof(DiffuseRec)));
+    w.dcode = reinterpret_cast<unsigned long long*>(take((size_t)B * 8));
+    w.dtex = reinterpret_cast<uint32_t*>(take((size_t)B * 4));
+    w.cnt = reinterpret_cast<uint32_t*>(take((size_t)B * RT_MAX_LIGHTS * 4));
+    w.ctr = reinterpret_cast<Counters*>(take(sizeof(Counters)));
+    w.tilebuf = nullptr;
+    w.srays = reinterpret_cast<float4*>(take((size_t)SRAYS * 2 * sizeof(float4))); w.srays_cap = SRAYS;
+    w.ovf_bytes = std::max<size_t>(256, (size_t)BLOCKS * ovf_cap * RT_BLOCK * sizeof(int));
+    w.ovf = reinterpret_cast<int*>(take(w.ovf_bytes));
+    if (!fits) return fail(c, RT_ERR_LIMIT, "rt_trace_static: this scene's shadow walk needs %d spill entries per lane, more than the scratch array holds", ovf_cap);
+
+    FrameD saved = c->fr;
+    rt_stats saved_stats = c->stats;
+    set_frame(c, &q);
+    auto restore = [&]() { c->fr = saved; c->stats = saved_stats; };
+    hipError_t e = hipMemcpyAsync(d_org, org, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dir, dir, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_px, pixel, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sm, sample, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_acc, 0, (size_t)n * 3 * sizeof(long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_nf, 0, (size_t)n * 4, c->stream);
+    if (e != hipSuccess) { restore(); return fail(c, RT_ERR_DEVICE, "rt_trace_static staging: %s", hipGetErrorString(e)); }
+    Source src{};
+    src.from_tiles = false;
+    src.total = (unsigned long long)n;
+    src.d_org = d_org; src.d_dir = d_dir; src.d_pixel = d_px; src.d_sample = d_sm;
+    src.max_depth = q.max_depth;
+    rc = run_wavefront(c, src, w, d_acc, d_nf, nullptr);
+    if (rc == RT_OK) {
+        hipLaunchKernelGGL(k_resolve, dim3(((uint32_t)n * 3 + 255) / 256), dim3(256), 0, c->stream, d_acc, d_nf, (uint32_t)n, 1, d_out);
+        e = hipMemcpyAsync(rgb, d_out, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, RT_ERR_DEVICE, "rt_trace_static: %s", hipGetErrorString(e));
+    }
+    restore();
     return rc;
 }
 
