@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- Mrays/s of the MI355X render loop on BASELINE config 5.
+"""bench.py -- Mrays/s of the MI355X render loop on BASELINE config 5, ms/frame on the mesh scenes.
 
 Workload (BASELINE.json configs[4]): synthetic 10 M-triangle soup + floor + one
 area light, 3840x2160, 16 spp, soft shadows (35 samples per light), depth 5, mesh tree depth 24,
 counter RNG seed 0.  One "step" = one full frame.  With --gpus N the frame's 32x32 tiles are dealt
-round-robin to the N ranks (one process per GPU, scene replicated) and the frame is assembled
-with one RCCL all-reduce (disjoint tiles, so the sum is a gather) -- strong scaling.
+to the N ranks (one process per GPU, scene replicated; ray-tracing_amd/dist.py) and the frame is
+assembled with one RCCL all-gather of packed tile slabs -- strong scaling.
 
-Prints ONE JSON line on rank 0 (see the repo's bench contract): value = rays of all ranks /
-max-over-ranks wall time; `roofline` for the dominant kernel (k_shadow) from HIP-event launch
-durations measured inside the library; `cpu_baseline` = the oracle (CPU restatement of the
-reference path, ThreadPool-equivalent) timed on this host on a bounded centred crop.
+Prints ONE JSON line on rank 0 (the repo's bench contract):
+  value        rays of all ranks / max-over-ranks wall time of the timed steps
+  roofline     for the dominant kernel, k_shadow. What binds it is VALU issue, not HBM: `achieved` = executed
+               VALU lane-operations per second (SQ_THREAD_CYCLES_VALU per ray from the PMC pass over this very
+               frame, profiles/c5_k_shadow_pmc.json, x the rays of a launch / the launch duration measured live
+               with HIP events inside the library), `peak` = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz. Beside it:
+               `hbm` (counter traffic vs 8 TB/s), `executed_bytes` (node and triangle records the walk requested
+               vs the L2 peak) and `reference_algorithm_equiv_GBps` (SURVEY 8(d)'s bytes per ray of the
+               reference's exhaustive traversal -- a speed-up figure, it exceeds the HBM peak because the GPU
+               walk stops at the first occluder, prunes and reads quantised nodes; results are bit-identical).
+  cpu_baseline the oracle (CPU restatement of the reference path, ThreadPool-equivalent) timed on this host on
+               a centred 256x256 crop with 0.6 x cores (main.cpp:61) and with all cores of this process.
+  config       also carries BASELINE's second half: ms/frame of the mesh scenes (C4 gorilla and cow) and C3.
 """
 import argparse
 import importlib
@@ -26,14 +35,64 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0          # ... aggregate L2 bandwidth
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12     # one wave64 VALU instruction per 4 cycles per SIMD: 39.3 T lane-ops/s
 PER_RAY_FILE = os.path.join(ROOT, "profiles", "c5_per_ray.json")
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "c5_k_shadow_pmc.json")
 CHECKSUM_FILE = os.path.join(ROOT, "profiles", "c5_checksum.json")   # frame checksums of the plain reference-order traversal
+
+SIDE_CONFIGS = {   # BASELINE configs 3 and 4: name -> (scene, width, height, spp, max_depth)
+    "C3_refraction_1080p": ("refraction", 1920, 1080, 30, 5),
+    "C4_mesh_gorilla_1080p": ("mesh_gorilla", 1920, 1080, 30, 50),
+    "C4_mesh_cow_1080p": ("mesh_cow", 1920, 1080, 30, 50),
+}
 
 
 def algorithmic_bytes_per_ray(n_node, n_tri):
     """N_node*64 + N_tri*48 + 32 (ray in) + 16 (hit out); shadow rays fetch no normals."""
     return n_node * 64.0 + n_tri * 48.0 + 32.0 + 16.0
+
+
+def load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def time_side_config(rt, torch, device, name):
+    """ms per frame of one of the 1080p configs on this GPU (1 warm-up frame, 3 timed)."""
+    scene_name, W, H, spp, depth = SIDE_CONFIGS[name]
+    scene = rt.HostScene(scene_name, 3, 12)
+    ctx = rt.Context(device)
+    try:
+        ctx.upload_scene(scene)
+        ctx.set_camera(rt.default_camera(W / H))
+        params = rt.make_params(W, H, spp=spp, max_depth=depth, light_samples=35, shadow_mode=0, jitter=1, seed=0)
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device=f"cuda:{device}")
+        tiles = rt.interleaved_tiles(W, H)
+
+        def step():
+            ctx.begin_frame(params)
+            for t in tiles:
+                ctx.render_tile(*t)
+            ctx.resolve_device(frame.data_ptr())
+            return ctx.stats()
+
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rays = 0
+        k = 3
+        for _ in range(k):
+            rays += step().rays
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"ms_per_frame": round(el / k * 1e3, 2), "mrays_per_s": round(rays / el / 1e6, 1), "spp": spp, "max_depth": depth,
+                "frame_checksum": float(frame.double().sum().item())}
+    finally:
+        ctx.close()
 
 
 def main():
@@ -47,8 +106,9 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--mesh-depth", type=int, default=24)
-    ap.add_argument("--cpu-crop", type=int, default=64, help="side of the centred crop the CPU baseline renders")
+    ap.add_argument("--cpu-crop", type=int, default=256, help="side of the centred crop the CPU baseline renders (SURVEY 8(d): 256)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the C3/C4 frames")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,6 +129,7 @@ def main():
 
     W, H = args.width, args.height
     name = f"soup:{args.ntris}"
+    key = f"{name}/d{args.mesh_depth}/{W}x{H}x{args.spp}"
     t0 = time.time()
     scene = rt.HostScene(name, 3, args.mesh_depth)
     t_build = time.time() - t0
@@ -79,15 +140,17 @@ def main():
     cam = rt.default_camera(W / H)
     ctx.set_camera(cam)
     params = rt.make_params(W, H, spp=args.spp, max_depth=args.depth, light_samples=35, shadow_mode=0, jitter=1, seed=0)
+    dev = f"cuda:{local_rank}"
     tiles = rtd.shard_tiles(W, H, rank, world, 32)
-    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+    gather = rtd.FrameGather(W, H, world, dev, 32)
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
 
     def step():
         ctx.begin_frame(params)
         for t in tiles:
             ctx.render_tile(*t)
         ctx.resolve_device(frame.data_ptr())       # runs the queued tiles, writes this rank's pixels
-        rtd.gather_frame(frame)                    # RCCL all-reduce: disjoint tiles -> gather
+        gather(frame, rank)                        # RCCL all-gather of the packed tile slabs + scatter
         return ctx.stats()
 
     def fence():
@@ -115,77 +178,100 @@ def main():
         n_closest += st.launches_closest
     fence()
     elapsed = time.perf_counter() - t0
-    dev = f"cuda:{local_rank}"
     elapsed = rtd.max_over_ranks(elapsed, dev)
+    my_shad = shad
     rays, prim, sec, shad = rtd.sum_counters([rays, prim, sec, shad], dev)
     checksum = float(frame.double().sum().item())
 
     if rank == 0:
+        # ---- BASELINE's second half: ms/frame on the mesh scenes (and C3), same kernels, this GPU ----
+        side = None
+        if world == 1 and not args.no_side:
+            side = {}
+            for cfg in SIDE_CONFIGS:
+                try:
+                    side[cfg] = time_side_config(rt, torch, local_rank, cfg)
+                except Exception as e:      # a side frame must not cost the headline line
+                    side[cfg] = {"error": str(e)[:200]}
         # ---- CPU baseline + per-ray algorithmic work, from the oracle (test infrastructure) ----
         cpu = None
-        per_ray = None
-        if os.path.exists(PER_RAY_FILE):
-            try:
-                per_ray = json.load(open(PER_RAY_FILE)).get(f"{name}/d{args.mesh_depth}/{W}x{H}x{args.spp}")
-            except Exception:
-                per_ray = None
+        per_ray = (load_json(PER_RAY_FILE) or {}).get(key)
         if world == 1 and not args.no_cpu:
             import oracle_lib as O
-            threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 64))
+            avail = len(os.sched_getaffinity(0))
+            if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+                avail = max(1, min(avail, int(os.environ["OMP_NUM_THREADS"])))     # the GPU box grants 16 cores per GPU
+            avail = min(avail, 64)
+            t_ref = max(1, int(avail * 0.6))                                        # main.cpp:61,204
             osc = O.Scene(name, 3, args.mesh_depth)
             oc = O.default_camera(W / H)
             op = O.make_params(W, H, spp=args.spp, max_depth=args.depth, light_samples=35, shadow_mode=0, jitter=1, seed=0)
-            c = args.cpu_crop
+            c = min(args.cpu_crop, W, H)
             x0, y0 = (W - c) // 2, (H - c) // 2
-            orgb, oprim, ost, secs = osc.render(oc, op, x0, y0, c, c, threads=threads)
-            orays = ost.rays_primary + ost.rays_secondary + ost.rays_shadow
-            got = frame[y0:y0 + c, x0:x0 + c].cpu().numpy()
-            q = np.abs(O.quantize(got) - O.quantize(orgb)).max()
-            cpu = {"value": round(orays / secs / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                   "sample": f"centred {c}x{c} crop of the {W}x{H} frame at {args.spp} spp ({orays} rays, {secs:.1f} s); "
-                             f"GPU frame vs oracle on the crop: max 8-bit delta {int(q)}"}
+            runs = []
+            q = ost = orays = None
+            for threads in sorted({t_ref, avail}):
+                orgb, oprim, ost, secs = osc.render(oc, op, x0, y0, c, c, threads=threads)
+                orays = ost.rays_primary + ost.rays_secondary + ost.rays_shadow
+                runs.append({"threads": threads, "value": round(orays / secs / 1e6, 4), "seconds": round(secs, 1)})
+                if q is None:
+                    got = frame[y0:y0 + c, x0:x0 + c].cpu().numpy()
+                    q = int(np.abs(O.quantize(got) - O.quantize(orgb)).max())
+            cpu = {"value": runs[-1]["value"], "unit": "Mrays/s", "cores": runs[-1]["threads"], "kind": "port",
+                   "runs": runs, "host_cpus_visible": os.cpu_count(), "cores_of_this_process": avail,
+                   "sample": f"centred {c}x{c} crop of the {W}x{H} frame at {args.spp} spp at the full-resolution camera ({orays} rays per run); "
+                             f"per-pixel tasks on {runs[0]['threads']} threads (0.6 x cores, the reference's default) and on {runs[-1]['threads']} (all cores of this process); "
+                             f"GPU frame vs oracle on the crop: max 8-bit delta {q}"}
             per_ray = {"shadow_nodes": ost.sh_node_visits / max(ost.rays_shadow, 1),
                        "shadow_tris": ost.sh_tri_tests / max(ost.rays_shadow, 1),
                        "closest_nodes": (ost.node_visits - ost.sh_node_visits) / max(ost.rays_primary + ost.rays_secondary, 1),
                        "closest_tris": (ost.tri_tests - ost.sh_tri_tests) / max(ost.rays_primary + ost.rays_secondary, 1)}
-        checksum_ok = None
-        try:
-            want = json.load(open(CHECKSUM_FILE)).get(f"{name}/d{args.mesh_depth}/{W}x{H}x{args.spp}/depth{args.depth}")
-            if want is not None:
-                checksum_ok = bool(want == checksum)
-        except Exception:
-            pass
+        want = (load_json(CHECKSUM_FILE) or {}).get(f"{key}/depth{args.depth}")
+        checksum_ok = None if want is None else bool(want == checksum)
         roof = None
-        if per_ray and n_shadow:
-            bpr = algorithmic_bytes_per_ray(per_ray["shadow_nodes"], per_ray["shadow_tris"])
-            rays_per_launch = shad / world / n_shadow if world > 1 else shad / n_shadow
-            avg_ms = ms_shadow / n_shadow
-            achieved = bpr * rays_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            if os.path.exists(TRAFFIC_FILE):
-                try:
-                    traffic = json.load(open(TRAFFIC_FILE)).get("k_shadow_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            traffic_rate = round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None     # measured HBM-side GB/s
-            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_rate": traffic_rate,
-                    "traffic_frac": round(traffic_rate / HBM_PEAK_GBS, 4) if traffic_rate else None, "kernel": "k_shadow",
-                    "avg_launch_ms": round(avg_ms, 3), "launches": n_shadow,
-                    "bytes_per_ray": round(bpr, 1), "rays_per_launch": round(rays_per_launch, 1),
+        pmc = (load_json(PMC_FILE) or {}).get(key)
+        if n_shadow:
+            rays_per_launch = my_shad / n_shadow
+            avg_s = ms_shadow / n_shadow * 1e-3
+            roof = {"kernel": "k_shadow", "avg_launch_ms": round(avg_s * 1e3, 3), "launches": n_shadow, "rays_per_launch": round(rays_per_launch, 1),
                     "closest_kernel_ms": round(ms_closest / max(n_closest, 1), 3)}
+            if pmc:
+                ops_per_ray = pmc["SQ_THREAD_CYCLES_VALU_per_launch"] / pmc["rays_per_launch"]
+                achieved = ops_per_ray * rays_per_launch / avg_s / 1e12
+                hbm_bytes = (2.0 * pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024.0 / pmc["rays_per_launch"] * rays_per_launch
+                ex_bpr = pmc["node_steps_per_ray"] * 64.0 + pmc["tri_steps_per_ray"] * 128.0 + 32.0
+                roof.update({
+                    "bound": "valu", "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 3), "unit": "Tlane-op/s",
+                    "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": round(hbm_bytes),
+                    "valu_lane_ops_per_ray": round(ops_per_ray, 1),
+                    "lanes_active_per_valu_inst": round(pmc["SQ_THREAD_CYCLES_VALU_per_launch"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU_per_launch"]), 4),
+                    "valu_busy_of_wave_slots": round(pmc["SQ_ACTIVE_INST_VALU_per_launch"] * pmc.get("waves_per_simd", 4) / pmc["SQ_WAVE_CYCLES_per_launch"], 4),
+                    "hbm": {"achieved": round(hbm_bytes / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(hbm_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4)},
+                    "executed_bytes": {"bytes_per_ray": round(ex_bpr, 1), "achieved": round(ex_bpr * rays_per_launch / avg_s / 1e9, 1),
+                                       "peak": L2_PEAK_GBS, "unit": "GB/s (L2)", "frac": round(ex_bpr * rays_per_launch / avg_s / 1e9 / L2_PEAK_GBS, 4)},
+                    "pmc_source": pmc.get("source")})
+            if per_ray:
+                bpr = algorithmic_bytes_per_ray(per_ray["shadow_nodes"], per_ray["shadow_tris"])
+                roof["reference_algorithm_bytes_per_ray"] = round(bpr, 1)
+                roof["reference_algorithm_equiv_GBps"] = round(bpr * rays_per_launch / avg_s / 1e9, 1)
+        cfg = {"workload": f"C5: synthetic {args.ntris}-triangle soup, {W}x{H}, {args.spp} spp, soft shadows "
+                           f"(35 samples/light), depth {args.depth}, mesh BVH depth {args.mesh_depth}, counter RNG",
+               "tiles": "32x32, round-robin per tile row with a hashed row offset", "parallelism": f"tile-sharded x{world}",
+               "gather": f"all-gather of packed tile slabs, {gather.bytes_sent_per_rank()} B per rank" if world > 1 else "none (one rank)",
+               "rays_primary": prim, "rays_secondary": sec, "rays_shadow": shad,
+               "kernel_ms_per_step": {"k_shadow": round(ms_shadow / args.steps, 2), "k_closest": round(ms_closest / args.steps, 2)},
+               "scene_build_s": round(t_build, 2), "upload_s": round(t_upload, 2), "frame_checksum": checksum,
+               "frame_checksum_matches_reference_order_traversal": checksum_ok}
+        if side:
+            cfg["ms_per_frame_mesh_scene"] = {k: v.get("ms_per_frame") for k, v in side.items() if k.startswith("C4")}
+            cfg["side_configs"] = side
         out = {
-            "metric": "Mrays/sec (primary+secondary+shadow)", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
+            "metric": "Mrays/sec (primary+secondary+shadow); ms/frame on mesh scene in config", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C5: synthetic {args.ntris}-triangle soup, {W}x{H}, {args.spp} spp, soft shadows "
-                                   f"(35 samples/light), depth {args.depth}, mesh BVH depth {args.mesh_depth}, counter RNG",
-                       "tiles": "32x32 round-robin over ranks", "parallelism": f"tile-sharded x{world}",
-                       "rays_primary": prim, "rays_secondary": sec, "rays_shadow": shad,
-                       "kernel_ms_per_step": {"k_shadow": round(ms_shadow / args.steps, 2), "k_closest": round(ms_closest / args.steps, 2)},
-                       "scene_build_s": round(t_build, 2), "upload_s": round(t_upload, 2), "frame_checksum": checksum, "frame_checksum_matches_reference_order_traversal": checksum_ok},
-            "roofline": roof, "cpu_baseline": cpu,
+            "config": cfg, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,11 +1,17 @@
 """Multi-GPU plumbing: one process per GPU, image-space tiles sharded across ranks, one collective.
 
 The render loop shards naturally (pixels are independent): every rank holds the whole
-scene, renders an interleaved subset of the 32x32 tiles into a zero-initialised full-size frame and
-the frames are summed with ONE all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests). Tiles are
-disjoint and every other pixel is +0.0, so the sum is a bit-exact gather.
+scene and renders the 32x32 tiles dealt to it. Tiles are dealt row by row, round-robin with a
+pseudo-random offset per tile row (cost per pixel is heavy-tailed, SURVEY 6: never bands, and with
+120 tiles per row and 2/4/8 ranks a plain round-robin would be column stripes). The frame is assembled
+with ONE all-gather of packed per-rank pixel slabs (RCCL over xGMI on GPUs, gloo in the CPU tests)
+followed by a device-side scatter: 1/world of the frame leaves every rank instead of the whole frame
+an all-reduce would move. Disjoint tiles, copies only: the gathered frame has the bits of a
+single-GPU render.
 """
 import os
+
+TILE = 32
 
 
 def rank_world():
@@ -25,24 +31,76 @@ def init(backend, local_rank=None):
     return rank, world
 
 
-def shard_tiles(width, height, rank, world, tile=32):
-    """Round-robin (interleaved) assignment: the cost per pixel is heavy-tailed, never use bands."""
+def row_offset(ty, world):
+    """Offset of tile row ty in the round-robin deal (a fixed integer hash, the same on every rank)."""
+    h = (ty * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x2C1B3C6D) & 0xFFFFFFFF
+    h ^= h >> 12
+    return h % world
+
+
+def tile_owner(tx, ty, world):
+    return (tx + row_offset(ty, world)) % world
+
+
+def shard_tiles(width, height, rank, world, tile=TILE):
+    """The tiles (x, y, w, h) of `rank`, in row-major order."""
     out = []
-    k = 0
-    for y in range(0, height, tile):
-        for x in range(0, width, tile):
-            if k % world == rank:
+    for ty, y in enumerate(range(0, height, tile)):
+        for tx, x in enumerate(range(0, width, tile)):
+            if tile_owner(tx, ty, world) == rank:
                 out.append((x, y, min(tile, width - x), min(tile, height - y)))
-            k += 1
     return out
 
 
-def gather_frame(frame):
-    """Sum of the per-rank partial frames (disjoint tiles) -> the full frame on every rank."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(frame, op=dist.ReduceOp.SUM)
-    return frame
+class FrameGather:
+    """Assembles the full frame from the ranks' disjoint tile sets: pack -> all-gather -> scatter.
+
+    Built once per (image size, world): per rank the flat pixel indices of its tiles (tile after tile),
+    padded to the longest rank by repeating its first pixel (a repeated index writes the same value
+    twice). `frame` is this rank's (H, W, 3) float32 tensor whose own tiles are rendered; after
+    __call__ it holds the whole image on every rank."""
+
+    def __init__(self, width, height, world, device, tile=TILE):
+        import torch
+        self.world = world
+        self.shape = (height, width, 3)
+        per_rank = []
+        for r in range(world):
+            idx = []
+            for (x, y, w, h) in shard_tiles(width, height, r, world, tile):
+                rows = torch.arange(y, y + h, dtype=torch.int64).unsqueeze(1) * width
+                cols = torch.arange(x, x + w, dtype=torch.int64).unsqueeze(0)
+                idx.append((rows + cols).reshape(-1))
+            per_rank.append(torch.cat(idx) if idx else torch.zeros(0, dtype=torch.int64))
+        self.counts = [int(t.numel()) for t in per_rank]
+        assert sum(self.counts) == width * height
+        self.slab = max(max(self.counts), 1)
+        padded = []
+        for t in per_rank:
+            fill = t[:1] if t.numel() else torch.zeros(1, dtype=torch.int64)
+            padded.append(torch.cat([t, fill.expand(self.slab - t.numel())]))
+        self.index = torch.stack(padded).to(device)            # (world, slab)
+        self.recv = torch.empty((world, self.slab, 3), dtype=torch.float32, device=device)
+
+    def bytes_sent_per_rank(self):
+        return self.slab * 12
+
+    def __call__(self, frame, rank):
+        import torch.distributed as dist
+        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return frame
+        assert tuple(frame.shape) == self.shape and frame.is_contiguous()
+        flat = frame.view(-1, 3)
+        mine = flat.index_select(0, self.index[rank])
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self.recv.view(-1, 3), mine)
+        else:
+            parts = [self.recv[r] for r in range(self.world)]
+            dist.all_gather(parts, mine)
+        flat.index_copy_(0, self.index.view(-1), self.recv.view(-1, 3))
+        return frame
 
 
 def sum_counters(values, device=None):
