@@ -1,14 +1,19 @@
 /*
  * ref_shim.cpp -- C entry points over the GL-free part of the reference,
  * compiled UNMODIFIED from /root/reference (include/Vec3.h, include/Line.h,
- * src/Trackball.cpp) into oracle/_ref/libref.so.  Test infrastructure only:
- * it pins the oracle's vector primitives, Ray/Line normalisation and
- * build_rotmatrix against the real reference code.  Everything else on the
- * path includes <GL/glut.h> and is unbuildable in this image.
+ * src/Trackball.cpp, include/stb_image.h) into oracle/_ref/libref.so.  Test
+ * infrastructure only: it pins the oracle's vector primitives, Ray/Line
+ * normalisation, build_rotmatrix and the image reader (the texels
+ * Material::loadTexture hands to the render loop, Material.h:128-138) against the
+ * real reference code.  Everything else on the path includes <GL/glut.h> and is
+ * unbuildable in this image.
  */
+#include <cstring>
 #include "Vec3.h"
 #include "Line.h"
 #include "Trackball.h"
+#define STB_IMAGE_IMPLEMENTATION          /* as main.cpp:34-35 */
+#include "stb_image.h"
 
 extern "C" {
 /* out[0]=dot, out[1..3]=cross, out[4]=length(a), out[5..7]=normalize(a),
@@ -42,4 +47,14 @@ void ref_build_rotmatrix(const float* q, float* m16) {
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m16[4 * i + j] = m[i][j];
 }
 void ref_trackball(float* q, float p1x, float p1y, float p2x, float p2y) { trackball(q, p1x, p1y, p2x, p2y); }
+/* Material::loadTexture (Material.h:129): stbi_load(file, &w, &h, &channels, 0). Copies up to cap bytes into out
+ * (may be null to query the size); returns 0, or -1 if the file does not decode. */
+int ref_stbi_load(const char* path, int* w, int* h, int* channels, unsigned char* out, long cap) {
+    unsigned char* px = stbi_load(path, w, h, channels, 0);
+    if (!px) return -1;
+    long n = (long)*w * *h * *channels;
+    if (out) memcpy(out, px, (size_t)(n < cap ? n : cap));
+    stbi_image_free(px);
+    return 0;
+}
 }

@@ -14,8 +14,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("RT_LIB", os.path.join(_HERE, "librtgpu.so"))   # RT_LIB: developer A/B knob
-DEFAULT_ASSET_DIR = os.path.join(ROOT, "tests", "golden", "models")
-DEFAULT_IMAGE_DIR = os.path.join(ROOT, "tests", "golden", "img")
+# data files of the reference's setup_* scenes (its assets/models/*.off and assets/img/**.ppm; data, not source)
+DEFAULT_ASSET_DIR = os.environ.get("RT_ASSET_DIR", os.path.join(ROOT, "assets", "models"))
+DEFAULT_IMAGE_DIR = os.environ.get("RT_IMAGE_DIR", os.path.join(ROOT, "assets", "img"))
 
 RT_OK = 0
 

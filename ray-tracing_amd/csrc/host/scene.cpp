@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
 #include <thread>
 
@@ -85,6 +86,16 @@ bool Mesh::loadOFF(const std::string& filename) {
     std::string header;
     unsigned int sizeV = 0, sizeT = 0, tmp = 0;
     in >> header >> sizeV >> sizeT >> tmp;
+    /* same read order as Mesh.cpp:10-21; unlike the reference, a file that ends early, does not parse or names a vertex
+     * that does not exist is refused (recomputeNormals would write out of bounds) instead of being used as it comes */
+    if (!in || sizeV > (1u << 31) || sizeT > (1u << 29)) { positions.clear(); triangles.clear(); return false; }
+    {   /* every vertex needs at least 6 bytes of text, every triangle 8: a header that promises more than the file holds is refused before the resize */
+        const std::streampos here = in.tellg();
+        in.seekg(0, std::ios::end);
+        const std::streampos end = in.tellg();
+        in.seekg(here);
+        if (here < 0 || end < here || (uint64_t)(end - here) < 5ull * sizeV + 7ull * sizeT) return false;
+    }
     positions.assign(sizeV, Vec3());
     triangles.assign(3 * (size_t)sizeT, 0u);
     for (unsigned int i = 0; i < sizeV; i++) in >> positions[i][0] >> positions[i][1] >> positions[i][2];
@@ -93,7 +104,10 @@ bool Mesh::loadOFF(const std::string& filename) {
         in >> s;
         for (unsigned int j = 0; j < 3; j++) in >> triangles[3 * (size_t)i + j];
     }
-    return true;
+    bool ok = (bool)in;
+    for (size_t i = 0; ok && i < triangles.size(); i++) ok = triangles[i] < sizeV;
+    if (!ok) { positions.clear(); triangles.clear(); }
+    return ok;
 }
 
 void Mesh::recomputeNormals() {
@@ -617,7 +631,7 @@ static bool readMaterial(std::istringstream& in, Material& m, size_t n_textures)
     for (int k = 0; k < 3; k++) in >> m.specular_material[k];
     in >> m.shininess >> m.type >> m.index_medium >> m.transparency >> m.reflectivity >> m.texture >> m.normalMap >> m.materialScale;
     if (!in) return false;
-    return m.texture < (int)n_textures && m.normalMap < (int)n_textures && m.type >= 0 && m.type <= 3;
+    return m.texture >= -1 && m.texture < (int)n_textures && m.normalMap >= -1 && m.normalMap < (int)n_textures && m.type >= 0 && m.type <= 3;
 }
 
 bool Scene::save(const std::string& filename) const {
@@ -684,6 +698,13 @@ bool Scene::load(const std::string& filename, std::string* why) {
             std::istringstream dims(line);
             dims >> kind >> im.width >> im.height >> im.channels;
             if (!dims || im.width <= 0 || im.height <= 0 || im.channels < 3 || im.channels > 4 || (int64_t)im.width * im.height > (1ll << 28)) return fail("bad texture header" + at);
+            {
+                const std::streampos here = in.tellg();
+                in.seekg(0, std::ios::end);
+                const std::streampos end = in.tellg();
+                in.seekg(here);
+                if (here < 0 || end < here || (uint64_t)(end - here) < (uint64_t)im.width * im.height * im.channels) return fail("truncated texture" + at);
+            }
             im.data.resize((size_t)im.width * im.height * im.channels);
             if (!block(im.data.data(), im.data.size())) return fail("truncated texture" + at);
             textures.push_back(std::move(im));
@@ -707,6 +728,13 @@ bool Scene::load(const std::string& filename, std::string* why) {
             ls >> nv >> nt;
             Material mat;
             if (!ls || nv == 0 || nt == 0 || nv > (1ull << 31) || nt > (1ull << 29) || !readMaterial(ls, mat, textures.size())) return fail("bad mesh header" + at);
+            {   /* the block must be in the file before anything is sized by an untrusted header */
+                const std::streampos here = in.tellg();
+                in.seekg(0, std::ios::end);
+                const std::streampos end = in.tellg();
+                in.seekg(here);
+                if (here < 0 || end < here || (uint64_t)(end - here) < nv * sizeof(Vec3) + 3 * nt * sizeof(uint32_t)) return fail("truncated mesh" + at);
+            }
             meshes.emplace_back();
             Mesh& m = meshes.back();
             m.material = mat;
@@ -919,24 +947,37 @@ int ray_trace_from_camera(rt_ctx* ctx, Scene& scene, const Camera& camera, int w
 /* ====================================================================== C facade */
 struct rth_scene { rth::Scene scene; rth::Settings settings; };
 
+/* No exception crosses the C-ABI (include/rtgpu.h): every body that can throw runs under this guard. */
+template <typename F>
+static int guarded(F body) {
+    try { return body(); }
+    catch (const std::bad_alloc&) { return RT_ERR_NOMEM; }
+    catch (...) { return RT_ERR_ARG; }
+}
+
 extern "C" {
-rth_scene* rth_scene_new(void) { return new rth_scene(); }
+rth_scene* rth_scene_new(void) { try { return new rth_scene(); } catch (...) { return nullptr; } }
 void rth_scene_free(rth_scene* s) { delete s; }
 void rth_set_asset_dir(const char* dir) { rth::set_asset_dir(dir); }
 void rth_set_image_dir(const char* dir) { rth::set_image_dir(dir); }
 int rth_add_texture(rth_scene* s, int width, int height, int channels, const uint8_t* texels) {
-    if (!s) return RT_ERR_ARG;
-    int idx = s->scene.addImage(width, height, channels, texels);
-    return idx < 0 ? RT_ERR_ARG : idx + 1;
+    if (!s || !texels) return RT_ERR_ARG;
+    return guarded([&] {
+        int idx = s->scene.addImage(width, height, channels, texels);
+        return idx < 0 ? (int)RT_ERR_ARG : idx + 1;
+    });
 }
 int rth_scene_setup(rth_scene* s, const char* name) {
     if (!s || !name) return RT_ERR_ARG;
-    return s->scene.setup(name) ? RT_OK : RT_ERR_ARG;
+    return guarded([&] { return s->scene.setup(name) ? (int)RT_OK : (int)RT_ERR_ARG; });
 }
 int rth_add_light(rth_scene* s, const float pos[3], float radius, const float color[3]) {
-    rth::Light l; l.pos = rth::Vec3(pos[0], pos[1], pos[2]); l.radius = radius; l.material = rth::Vec3(color[0], color[1], color[2]);
-    s->scene.lights.push_back(l);
-    return RT_OK;
+    if (!s || !pos || !color) return RT_ERR_ARG;
+    return guarded([&] {
+        rth::Light l; l.pos = rth::Vec3(pos[0], pos[1], pos[2]); l.radius = radius; l.material = rth::Vec3(color[0], color[1], color[2]);
+        s->scene.lights.push_back(l);
+        return (int)RT_OK;
+    });
 }
 static rth::Material fromC(const rt_material* m) {
     rth::Material r;
@@ -953,65 +994,87 @@ static bool imagesOk(const rth_scene* s, const rth::Material& m) {
     return m.texture >= -1 && m.texture < n && m.normalMap >= -1 && m.normalMap < n;
 }
 int rth_add_square(rth_scene* s, const float verts[12], const rt_material* m) {
-    if (!s || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
-    rth::Square q;
-    for (int j = 0; j < 4; j++) q.vertices[j] = rth::Vec3(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]);
-    q.material = fromC(m);
-    s->scene.squares.push_back(q);
-    return RT_OK;
+    if (!s || !verts || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
+    return guarded([&] {
+        rth::Square q;
+        for (int j = 0; j < 4; j++) q.vertices[j] = rth::Vec3(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]);
+        q.material = fromC(m);
+        s->scene.squares.push_back(q);
+        return (int)RT_OK;
+    });
 }
 int rth_add_sphere(rth_scene* s, const float c[3], float radius, const rt_material* m) {
-    if (!s || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
-    rth::Sphere sp; sp.m_center = rth::Vec3(c[0], c[1], c[2]); sp.m_radius = radius; sp.material = fromC(m);
-    s->scene.spheres.push_back(sp);
-    return RT_OK;
+    if (!s || !c || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
+    return guarded([&] {
+        rth::Sphere sp; sp.m_center = rth::Vec3(c[0], c[1], c[2]); sp.m_radius = radius; sp.material = fromC(m);
+        s->scene.spheres.push_back(sp);
+        return (int)RT_OK;
+    });
 }
 int rth_add_mesh(rth_scene* s, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt, const rt_material* m) {
-    if (!s || nv <= 0 || nt <= 0 || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
+    if (!s || !verts || !tris || nv <= 0 || nt <= 0 || nv > (1ll << 31) || nt > (1ll << 29) || !imagesOk(s, fromC(m))) return RT_ERR_ARG;
     for (int64_t i = 0; i < 3 * nt; i++) if (tris[i] >= (uint64_t)nv) return RT_ERR_ARG;
-    s->scene.meshes.emplace_back();
-    rth::Mesh& ms = s->scene.meshes.back();
-    ms.positions.resize((size_t)nv);
-    for (int64_t i = 0; i < nv; i++) ms.positions[i] = rth::Vec3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
-    ms.triangles.assign(tris, tris + 3 * nt);
-    ms.build_arrays();
-    ms.material = fromC(m);
-    return RT_OK;
+    return guarded([&] {
+        rth::Mesh ms;
+        ms.positions.resize((size_t)nv);
+        for (int64_t i = 0; i < nv; i++) ms.positions[i] = rth::Vec3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+        ms.triangles.assign(tris, tris + 3 * nt);
+        ms.build_arrays();
+        ms.material = fromC(m);
+        s->scene.meshes.push_back(std::move(ms));
+        return (int)RT_OK;
+    });
 }
 int rth_build(rth_scene* s, int top_depth, int mesh_depth) {
     if (!s || top_depth < 0 || mesh_depth < 0) return RT_ERR_ARG;
     if (top_depth > RT_MAX_TOP_DEPTH || mesh_depth > RT_MAX_TREE_DEPTH) return RT_ERR_LIMIT;
-    s->settings.tree_subdivide = (unsigned)mesh_depth;
-    s->scene.applySettings(s->settings);
-    s->scene.topDepthLimit = top_depth;
-    s->scene.buildSceneBvh();
-    s->scene.flatten();
-    return RT_OK;
+    return guarded([&] {
+        s->settings.tree_subdivide = (unsigned)mesh_depth;
+        s->scene.applySettings(s->settings);
+        s->scene.topDepthLimit = top_depth;
+        s->scene.buildSceneBvh();
+        s->scene.flatten();
+        return (int)RT_OK;
+    });
 }
-const rt_scene_desc* rth_scene_desc(rth_scene* s) { return &s->scene.flatten(); }
+const rt_scene_desc* rth_scene_desc(rth_scene* s) {
+    if (!s) return nullptr;
+    try { return &s->scene.flatten(); } catch (...) { return nullptr; }
+}
 int rth_ray_trace_from_camera(rt_ctx* ctx, rth_scene* s, const rt_camera* cam, const rt_render_params* p, const char* path, double* seconds) {
     if (!ctx || !s || !cam || !p) return RT_ERR_ARG;
     rth::Camera c;
     c.x = cam->x; c.y = cam->y; c.z = cam->z; c._zoom = cam->zoom;
     for (int i = 0; i < 4; i++) c.curquat[i] = cam->quat[i];
     c.fovAngle = cam->fovy_deg; c.aspectRatio = cam->aspect; c.nearPlane = cam->znear; c.farPlane = cam->zfar;
-    return rth::ray_trace_from_camera(ctx, s->scene, c, p->img_w, p->img_h, p, path, seconds);
+    return guarded([&] { return rth::ray_trace_from_camera(ctx, s->scene, c, p->img_w, p->img_h, p, path, seconds); });
 }
-int rth_write_ppm(const char* path, const float* rgb, int w, int h) { return rth::write_ppm(path, rgb, w, h); }
-int rth_scene_save(rth_scene* s, const char* path) { return (s && path && s->scene.save(path)) ? RT_OK : RT_ERR_ARG; }
+int rth_write_ppm(const char* path, const float* rgb, int w, int h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return RT_ERR_ARG;
+    return guarded([&] { return rth::write_ppm(path, rgb, w, h); });
+}
+int rth_scene_save(rth_scene* s, const char* path) {
+    if (!s || !path) return RT_ERR_ARG;
+    return guarded([&] { return s->scene.save(path) ? (int)RT_OK : (int)RT_ERR_ARG; });
+}
 int rth_scene_load(rth_scene* s, const char* path) {
     if (!s || !path) return RT_ERR_ARG;
-    std::string why;
-    if (!s->scene.load(path, &why)) { fprintf(stderr, "[rthost] %s\n", why.c_str()); return RT_ERR_ARG; }
-    return RT_OK;
+    return guarded([&] {
+        std::string why;
+        if (!s->scene.load(path, &why)) { fprintf(stderr, "[rthost] %s\n", why.c_str()); return (int)RT_ERR_ARG; }
+        return (int)RT_OK;
+    });
 }
 int rth_load_off(const char* path, float* verts, int64_t max_v, uint32_t* tris, int64_t max_t, int64_t* nv, int64_t* nt) {
-    rth::Mesh m;
-    if (!m.loadOFF(path)) return RT_ERR_ARG;
-    if (nv) *nv = (int64_t)m.positions.size();
-    if (nt) *nt = (int64_t)m.triangleCount();
-    if (verts) for (int64_t i = 0; i < (int64_t)m.positions.size() && i < max_v; i++) for (int k = 0; k < 3; k++) verts[3 * i + k] = m.positions[i][k];
-    if (tris) for (int64_t i = 0; i < (int64_t)m.triangleCount() && i < max_t; i++) for (int k = 0; k < 3; k++) tris[3 * i + k] = m.triangles[3 * i + k];
-    return RT_OK;
+    if (!path) return RT_ERR_ARG;
+    return guarded([&] {
+        rth::Mesh m;
+        if (!m.loadOFF(path)) return (int)RT_ERR_ARG;
+        if (nv) *nv = (int64_t)m.positions.size();
+        if (nt) *nt = (int64_t)m.triangleCount();
+        if (verts) for (int64_t i = 0; i < (int64_t)m.positions.size() && i < max_v; i++) for (int k = 0; k < 3; k++) verts[3 * i + k] = m.positions[i][k];
+        if (tris) for (int64_t i = 0; i < (int64_t)m.triangleCount() && i < max_t; i++) for (int k = 0; k < 3; k++) tris[3 * i + k] = m.triangles[3 * i + k];
+        return (int)RT_OK;
+    });
 }
 }

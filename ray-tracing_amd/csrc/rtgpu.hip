@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -77,6 +78,7 @@ struct rt_ctx {
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
     hipEvent_t ev_frame_a = nullptr, ev_frame_b = nullptr;
+    size_t lds_max = 65536;     /* sharedMemPerBlock of the device */
     unsigned char* static_scratch = nullptr;   /* this device's copy of rt_static_scratch (rt_trace_static) */
 };
 
@@ -286,9 +288,10 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
     /* threads per block of k_closest (one append atomic per block): big blocks where rays are cheap and the appends would
      * dominate, one wave per block under deep mesh trees, where a block would wait for its slowest wave
      * (64 / 128 / 256 threads: refraction scene 13.9 / 10.7 / 9.3 ms, gorilla 13.5 / 12.0 / 11.1, C5 reduced 25.6 / 28.0 / 28.6) */
-    const uint32_t cblock_light = (c->sc.stack_cap - c->sc.top_cap - 2 > 16) ? 64u : (uint32_t)RT_CBLOCK;
+    uint32_t cblock_light = (c->sc.stack_cap - c->sc.top_cap - 2 > 16) ? 64u : (uint32_t)RT_CBLOCK;
+    if (lds_bytes_closest(c, RT_CBLOCK) + 64 > c->lds_max) cblock_light = 64u;      /* (deep sub-trees under a shallow tree: the big block's stacks would not fit) */
     uint32_t cblock = cblock_light;
-    if (const char* e = getenv("RT_CBLOCK")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) cblock = (uint32_t)v; }
+    if (const char* e = getenv("RT_CBLOCK")) { int v = atoi(e); if ((v == 64 || v == 128 || v == 256) && lds_bytes_closest(c, v) + 64 <= c->lds_max) cblock = (uint32_t)v; }
 
     while (done < src.total || top > 0) {
         /* 1. top up with fresh primaries */
@@ -383,7 +386,8 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                  * persistent kernel. Whether that pays is the scene's matter (a gorilla on a floor: most rays pass it by;
                  * C5's soup fills the scene: every ray enters it), so the first launch on a scene looks at the share of
                  * deferred rays and decides for the scene. */
-                const bool front = c->sc.quant_ok && c->front_state != 0;
+                const size_t front_lds = (size_t)c->sc.top_cap * RT_FBLOCK * sizeof(int) + (RT_FBLOCK / 64 + 2) * sizeof(uint32_t);
+                const bool front = c->sc.quant_ok && c->front_state != 0 && front_lds <= c->lds_max;
                 EventPair* e2 = nullptr;
                 if (front) {
                     HIP_TRY(c, hipMemsetAsync(&d_ctr->deferred, 0, sizeof(unsigned long long), c->stream));
@@ -392,7 +396,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                         HIP_TRY(c, hipEventRecord(e2->a, c->stream));
                     }
                     hipLaunchKernelGGL(k_shadow_front, dim3((uint32_t)((threads + RT_FBLOCK - 1) / RT_FBLOCK)), dim3(RT_FBLOCK),
-                                       (size_t)c->sc.top_cap * RT_FBLOCK * sizeof(int) + (RT_FBLOCK / 64 + 2) * sizeof(uint32_t), c->stream, c->sc, c->fr,
+                                       front_lds, c->stream, c->sc, c->fr,
                                        w.drec + r0, w.dcode + r0, nr, S, cnt0, w.srays, &d_ctr->deferred, &d_ctr->deferred_sum);
                     blocks_now = (unsigned long long)w.persistent_blocks;      /* (how many rays come through is on the device) */
                     front_rays += threads;
@@ -820,6 +824,16 @@ const char* tree_defect(const rt_bvh_node* nodes, int64_t n_nodes, int32_t root,
 }
 
 int check_desc(rt_ctx* c, const rt_scene_desc* d) {
+    /* counts and the arrays they size, before anything is read through them */
+    if (d->n_materials < 0 || d->n_lights < 0 || d->n_squares < 0 || d->n_spheres < 0 || d->n_meshes < 0 || d->n_verts < 0 || d->n_tris < 0 ||
+        d->n_mesh_nodes < 0 || d->n_mesh_leaves < 0 || d->n_top_nodes < 0 || d->n_top_leaves < 0 || d->n_top_items < 0 || d->n_textures < 0)
+        return fail(c, RT_ERR_ARG, "negative count in the scene description");
+    if ((d->n_materials && !d->materials) || (d->n_lights && !d->lights) || (d->n_squares && !d->squares) || (d->n_spheres && !d->spheres) ||
+        (d->n_meshes && !d->meshes) || (d->n_verts && (!d->positions || !d->normals)) || (d->n_tris && (!d->tri_indices || !d->mesh_items)) ||
+        (d->n_mesh_nodes && !d->mesh_nodes) || (d->n_mesh_leaves && !d->mesh_leaves) || (d->n_top_nodes && !d->top_nodes) ||
+        (d->n_top_leaves && !d->top_leaves) || (d->n_top_items && !d->top_items))
+        return fail(c, RT_ERR_ARG, "null array with a non-zero count in the scene description");
+    if ((int64_t)d->n_squares + d->n_spheres + d->n_meshes > 0x3FFFFFFF) return fail(c, RT_ERR_LIMIT, "too many objects");
     if (d->n_lights > RT_MAX_LIGHTS) return fail(c, RT_ERR_LIMIT, "more than %d lights", RT_MAX_LIGHTS);
     if (d->n_materials <= 0 && (d->n_squares + d->n_spheres + d->n_meshes) > 0) return fail(c, RT_ERR_ARG, "no materials");
     if (d->n_textures < 0 || (d->n_textures > 0 && !d->textures)) return fail(c, RT_ERR_ARG, "textures");
@@ -960,8 +974,15 @@ void rt_shutdown(rt_ctx* c) {
     delete c;
 }
 
+static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d);
 int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     if (!c || !d) return RT_ERR_ARG;
+    /* the host-side preparation sizes vectors by the caller's counts: no exception may cross the ABI */
+    try { return upload_scene_impl(c, d); }
+    catch (const std::bad_alloc&) { free_scene(c); return fail(c, RT_ERR_NOMEM, "out of host memory while preparing the scene"); }
+    catch (...) { free_scene(c); return fail(c, RT_ERR_ARG, "scene preparation failed"); }
+}
+static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = check_desc(c, d);
     if (rc) return rc;
@@ -1306,6 +1327,20 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     sc.wstack_cap = sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 3;
     sc.has_sub = subs.empty() ? 0 : 1;
     sc.quant_ok = (quant_ok && !getenv("RT_SHADOW_EXACT_NODES")) ? 1 : 0;
+    {   /* The per-lane stacks of the walks live in LDS (4 bytes x entries x threads of the block; k_shadow's wide stack spills
+         * beyond stack_cap). What a launch may ask for is a documented limit, not a launch failure at rt_flush: the one-wave
+         * build of k_closest / k_intersect must fit (the 256-thread build is only chosen when it fits, run_wavefront). */
+        hipDeviceProp_t prop;
+        size_t lds_max = 65536;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.sharedMemPerBlock > 0) lds_max = prop.sharedMemPerBlock;
+        const size_t need = (size_t)std::max(sc.cstack_cap, sc.stack_cap) * RT_BLOCK * sizeof(int) + 4096;
+        if (need > lds_max) {
+            free_scene(c);
+            return fail(c, RT_ERR_LIMIT, "traversal stacks need %zu bytes of LDS per block (%d entries per lane: tree depth %d, sub-tree depth %d), the device allows %zu",
+                        need, std::max(sc.cstack_cap, sc.stack_cap), max_mesh_depth, max_wide_sub_depth, lds_max);
+        }
+        c->lds_max = lds_max;
+    }
     if (c->debug) fprintf(stderr, "[rtgpu] scene: %lld mesh nodes, depth %d, quantised shadow nodes %s\n", (long long)d->n_mesh_nodes, max_mesh_depth,
                           sc.quant_ok ? "on" : "off");
     c->sc = sc;

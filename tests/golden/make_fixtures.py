@@ -1,4 +1,4 @@
-"""Regenerates the data fixtures under tests/golden/ from the reference checkout.
+"""Regenerates the data files under assets/ (repo root) from the reference checkout.
 
 Run in the build container only (needs /root/reference):  python tests/golden/make_fixtures.py
 
@@ -13,7 +13,7 @@ import os
 import shutil
 
 REF = "/root/reference/assets/models"
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "assets")
 FILES = ["flamingo.off", "gorilla18_fixed.obj.off", "cow.off", "triangle.off", "cube.off"]
 IMG_REF = "/root/reference/assets/img"
 IMAGES = ["normalMaps/n3.ppm", "sphereTextures/s4.ppm"]

@@ -8,8 +8,8 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ASSET_DIR = os.path.join(ROOT, "tests", "golden", "models")
-IMAGE_DIR = os.path.join(ROOT, "tests", "golden", "img")
+ASSET_DIR = os.path.join(ROOT, "assets", "models")
+IMAGE_DIR = os.path.join(ROOT, "assets", "img")
 
 
 class Material(C.Structure):

@@ -146,3 +146,28 @@ def test_rotmatrix_matches_the_compiled_trackball():
         R.ref_build_rotmatrix(q.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p))
         O.lib().orc_rotmatrix(q.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("rel", ["normalMaps/n3.ppm", "sphereTextures/s4.ppm"])
+def test_image_readers_equal_stbi_load(rel):
+    """The texels the render loop samples (Material.h:86-104) are what stbi_load returns (Material.h:128-138). The
+    reference's own stb_image.h, compiled unmodified, must give the bytes, width, height and channel count that the
+    oracle's reader and the host mirror's reader (librtgpu.so, rth::Scene::loadImage) produce for the reference's images."""
+    import importlib
+    R = C.CDLL(REF_SO)
+    R.ref_stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_long]
+    path = os.path.join(O.IMAGE_DIR, rel)
+    w, h, ch = C.c_int(), C.c_int(), C.c_int()
+    assert R.ref_stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(ch), None, 0) == 0
+    want = np.zeros((h.value, w.value, ch.value), np.uint8)
+    assert R.ref_stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(ch), want.ctypes.data_as(C.c_void_p), want.size) == 0
+    assert ch.value == 3 and want.size > 0
+    got = O.load_ppm(path)
+    assert got.shape == want.shape and np.array_equal(got, want), "oracle reader differs from stbi_load"
+    # the host mirror loads the same two files in setup_reflexion_chamber (normal map of the floor) / on request
+    rt = importlib.import_module("ray-tracing_amd")
+    hs = rt.HostScene("reflexion_chamber", 3, 12)
+    tex = hs.arrays()["textures"]
+    if rel.endswith("n3.ppm"):
+        assert any(t.shape == want.shape and np.array_equal(t, want) for t in tex), "host mirror's texels differ from stbi_load"
