@@ -108,7 +108,14 @@ struct DScene {
      * byte offsets of tnodes, tleaves, titems, squares, spheres, meshes inside top_blob */
     const float4* top_blob;
     int32_t top_blob_bytes;
-    int32_t top_off[6];
+    int32_t top_off[7];         /* ... and tsub: per top-level leaf the root of the sub-tree over its objects, or LINK_NONE */
+    int32_t has_topsub;         /* some top-level leaves carry a sub-tree over their objects (rtgpu.hip) */
+};
+/* head of section 6 of top_blob, in front of tsub */
+struct TopFrame {
+    DMesh frame;                /* frame (qmin, qstep, amax) of the 16-bit planes of the sub-trees of top-level leaves: the whole scene */
+    float omin[3], omax[3];     /* rays that start outside this box take the plain item scan (the object boxes assume origins inside) */
+    float pad[2];
 };
 
 struct Ray { F3 o, d, inv; };
@@ -161,8 +168,20 @@ RT_DEV bool tri_test(const Ray& r, float4 q0, float4 q1, float4 q2, float4 q3, f
     float u2 = (len(cross(sub(c1, c0), sub(P, c0))) * 0.5f) / area;
     float sum = u0 + u1 + u2;
     if ((double)sum < 0.9999 || (double)sum > 1.00001) return false;   /* Triangle.h:105 */
-    F3 cd = normalized(sub(P, r.o));                             /* Triangle.h:94-95 */
-    if (dot(cd, r.d) < 0) return false;                          /* Triangle.h:96 */
+    /* Triangle.h:94-96: reject if dot(normalize(P - o), d) < 0. The normalisation (a correctly rounded sqrt and three
+     * divisions) only matters when that cosine is within rounding of zero: the computed value differs from the true
+     * cosine c of the float vectors by less than 4e-7 |d|, and the plain product s = (P - o).d equals c |P - o| up to
+     * 2e-7 |P - o| |d|. So for |s| > 1e-4 |P - o| (|d| is 1 within rounding: Line.h:15) the sign of s IS the sign the
+     * reference computes, and the exact evaluation is kept for the rest (and for lengths whose square leaves the
+     * normal float range, where the reference's own arithmetic degenerates: NaN and overflow compare false here). */
+    F3 v = sub(P, r.o);
+    float sd = dot(v, r.d), vv = sqlen(v);
+    if (vv > 1e-30f && vv < 1e30f && sd * sd > 1e-8f * vv) {
+        if (sd < 0) return false;
+    } else {
+        F3 cd = normalized(v);                                   /* Triangle.h:94-95 */
+        if (dot(cd, r.d) < 0) return false;                      /* Triangle.h:96 */
+    }
     t_out = len(sub(r.o, P));                                    /* Triangle.h:110 */
     w0 = u0; w1 = u1; w2 = u2;
     return true;

@@ -44,6 +44,7 @@ struct Counters {
     unsigned long long deferred_sum; /* ... to all launches of this frame */
     unsigned long long sh_node_steps, sh_tri_steps, sh_other_steps, sh_loop_iters;   /* RT_COUNT=1 diagnostics */
     unsigned long long sh_node_iters, sh_tri_iters, sh_top_iters, sh_top_lanes;
+    unsigned long long sh_m1_node, sh_m1_tri, sh_m1_rays;   /* steps taken and rays finished in mode 1 (the second walk of shadow_walk) */
     unsigned long long sh_clk_refill, sh_clk_top, sh_clk_node, sh_clk_tri;             /* wave clocks per section (s_memtime) */      /* wave iterations per phase; lanes entering the top-level step */
 };
 struct TileD { int32_t x0, y0, w, h; unsigned long long first; };
@@ -63,7 +64,10 @@ RT_DEV int lds_index(int k, int stride) { return k * stride; }
 #define LINK_NONE ((int)0x80000000)
 #define WIDE_UNPRUNED 0x40000000    /* on a link to a 4-wide shadow node: do not prune by distance in that node */
 #define WIDE_SUB 0x20000000         /* ... the node belongs to the sub-tree of a fat leaf: the reference's tMax does not apply */
-#define WIDE_INDEX 0x1FFFFFFF
+#define WIDE_LINE 0x10000000        /* ... the node holds a sphere of a top-level leaf: its boxes are tested against the ray's whole line (a tangent hit may lie behind the origin, Sphere.h:113) */
+#define WIDE_INDEX 0x0FFFFFFF
+#define TOP_ITEM 0x20000000u        /* on a record index: not a triangle record but a top-level object ordinal (leaf of the sub-tree over the objects of a top-level leaf) */
+#define LINK_SENTINEL (-1)          /* on a lane's stack: below this entry lies the walk of a top-level leaf's sub-tree (scene frame), above it a mesh walk */
 #define TRI_SUB 0x40000000u         /* on a record index: a run inside a fat leaf (reached through the leaf's sub-tree) */
 #define TRI_LEAF_END 2u             /* record word 2.w: bit 0 = last of its run, bit 1 = last of its reference leaf */
 RT_DEV uint32_t leaf_first(int link) { return (uint32_t)(-2 - link); }
@@ -104,14 +108,14 @@ RT_DEV void quant_setup(QuantRay& q, const Ray& r, const DMesh& m) {
     q.rot[2] = r.inv.z < 0.0f ? 16u : 0u;
 }
 /* conservative entry time of one quantised box (three packed plane pairs); hit = the slab is not empty within [0, lim] */
-RT_DEV float quant_entry(uint32_t wx, uint32_t wy, uint32_t wz, const QuantRay& s, float lim, bool& hit) {
+RT_DEV float quant_entry(uint32_t wx, uint32_t wy, uint32_t wz, const QuantRay& s, float lim, bool& hit, float lo = 0.0f) {
     wx = __builtin_amdgcn_alignbit(wx, wx, s.rot[0]);
     wy = __builtin_amdgcn_alignbit(wy, wy, s.rot[1]);
     wz = __builtin_amdgcn_alignbit(wz, wz, s.rot[2]);
     float a = __builtin_fmaf((float)(wx & 0xFFFFu), s.qa.x, s.qn.x), d = __builtin_fmaf((float)(wx >> 16), s.qa.x, s.qf.x);
     float b = __builtin_fmaf((float)(wy & 0xFFFFu), s.qa.y, s.qn.y), e = __builtin_fmaf((float)(wy >> 16), s.qa.y, s.qf.y);
     float c = __builtin_fmaf((float)(wz & 0xFFFFu), s.qa.z, s.qn.z), f = __builtin_fmaf((float)(wz >> 16), s.qa.z, s.qf.z);
-    float tMin = fmaxf(fmaxf(fmaxf(a, b), c), 0.0f);
+    float tMin = fmaxf(fmaxf(fmaxf(a, b), c), lo);
     float tMax = fminf(fminf(fminf(d, e), f), lim);
     hit = tMin <= tMax;
     return tMin;
@@ -781,6 +785,7 @@ RT_DEV void shadow_restart(const DScene& sc, ShadowLane& s, int mode, int limit)
     s.ts = (uint32_t)mode | ((uint32_t)limit << 20);
     if (mode == 1) s.bound = 3.4028233e38f;             /* (mode 0: the refill has put lightDistance there) */
     s.tlink = sc.top_root; s.top_pos = s.top_end = 0;
+    s.tri_pos = TRI_NONE;                               /* (at the top level this word only ever holds an object handed over by a leaf's sub-tree) */
     s.st = ST_TOP;
 }
 RT_DEV void shadow_finish(ShadowLane& s, bool occ, uint32_t* cnt) {
@@ -795,46 +800,75 @@ RT_DEV void shadow_on_hit(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     shadow_restart(sc, s, 1, visited);
 }
 /* the top-level tables as k_shadow reads them: in global memory, or its LDS copy (generic pointers) */
-struct TopTables { const float4* tnodes; const uint2* tleaves; const uint32_t* titems; const float4* squares; const float4* spheres; const DMesh* meshes; };
+struct TopTables { const float4* tnodes; const uint2* tleaves; const uint32_t* titems; const float4* squares; const float4* spheres; const DMesh* meshes; const TopFrame* tf; const int* tsub; };
 #define RT_TOP_LDS_MAX 2048
-/* top-level state machine: runs until the ray ends or enters a mesh tree */
-template <bool QUANT>
-RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane& s, int* stk, int stride, uint32_t* cnt) {
+struct WideStack { int* lds; int* ovf; int lds_cap; const TopFrame* tf; };
+RT_DEV void wpush(const WideStack& w, int& sp, int link);
+/* one object of a top-level leaf: a square or sphere is tested on the spot, a mesh is entered (st = ST_MESH on return).
+ * Returns true if the caller has to return (the ray ended, restarted in mode 1, or sits in a mesh now). */
+template <bool QUANT, bool IN_SUB>     /* IN_SUB: reached through the sub-tree of its top-level leaf (the lane's s.q is the scene's frame then) */
+RT_DEV bool shadow_top_item(const DScene& sc, const TopTables& tt, ShadowLane& s, int ord, const WideStack& w, uint32_t* cnt) {
+    /* The caller's loop runs over the objects of a leaf with the ray fixed, and the compiler would hoist every product of
+     * ray components out of it (a = d.d, 4a, the plane times of the mesh frame test ...) and keep them in registers across
+     * the whole kernel loop, which this kernel cannot afford (k_shadow sits at its register limit: they end up spilled).
+     * Values that pass through an empty asm are opaque per call: nothing is hoisted, nothing is computed twice. */
+    asm volatile("" : "+v"(s.r.d.x), "+v"(s.r.d.y), "+v"(s.r.d.z), "+v"(s.r.inv.x), "+v"(s.r.inv.y), "+v"(s.r.inv.z));
+    if (ord < sc.n_squares) {
+        const float4* q = tt.squares + 4 * ord;
+        float t, u, v;
+        if (square_test(s.r, q[0], q[1], q[2], q[3], t, u, v) && t <= s.bound) { shadow_on_hit(sc, s, cnt); return true; }
+        return false;
+    }
+    if (ord < sc.n_squares + sc.n_spheres) {
+        const float4* q = tt.spheres + 2 * (ord - sc.n_squares);
+        float t; F3 n;
+        if (sphere_test(s.r, q[0], t, n) && t <= s.bound) { shadow_on_hit(sc, s, cnt); return true; }
+        return false;
+    }
+    DMesh m = tt.meshes[ord - sc.n_squares - sc.n_spheres];
+    /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter - slack > bound*1.00002 is
+     * still conservative and costs one compare per child */
+    s.prune_t = (s.ts & TS_MODE) == 0u ? s.bound * 1.00002f : INFINITY;
+    s.prune_raw = s.prune_t;
+    if (QUANT) s.prune_t = fminf(100.0f, s.prune_t);     /* tMax of AABB::intersect */
+    else s.maxinv = max_abs_inv(s.r);
+    if (QUANT) {
+        quant_setup(s.q, s.r, m);
+        /* The reference tests no box for the mesh as a whole (Mesh.cpp:97-123 starts at the root's
+         * children), but every box of the shadow tree lies inside the mesh's plane frame: a ray that
+         * misses the whole frame (or reaches it beyond the distance of interest) cannot reach a leaf,
+         * and stays at the top level -- scenes with dozens of meshes are mostly such visits. */
+        if (m.wroot >= 0) {
+            bool hit;
+            quant_entry(0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, s.q, (m.wroot & WIDE_UNPRUNED) ? 100.0f : s.prune_t, hit);
+            if (!hit) {
+                if (IN_SUB) quant_setup(s.q, s.r, tt.tf->frame);      /* (rare: the object's box in the sub-tree is this frame, rounded the other way) */
+                return false;
+            }
+        }
+    }
+    if (IN_SUB) wpush(w, s.msp, LINK_SENTINEL);      /* what lies below on the stack belongs to the walk of the leaf's sub-tree */
+    else s.msp = sc.top_cap;
+    s.link = QUANT ? m.wroot : m.root; s.tri_pos = TRI_NONE;
+    s.st = ST_MESH;
+    return true;
+}
+/* top-level state machine: runs until the ray ends or enters a mesh tree (or, TOPSUB, the sub-tree of a top-level leaf) */
+template <bool QUANT, bool TOPSUB>
+RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane& s, int* stk, int stride, uint32_t* cnt, const WideStack& w) {
+    if (TOPSUB && s.tri_pos != TRI_NONE) {
+        /* the walk of a leaf's sub-tree has reached an object (shadow_quant_step); afterwards that walk goes on */
+        const int ord = (int)(s.tri_pos & ~TOP_ITEM);
+        s.tri_pos = TRI_NONE;
+        if (shadow_top_item<QUANT, true>(sc, tt, s, ord, w, cnt)) return;
+        s.link = LINK_NONE;
+        s.st = ST_MESH;
+        return;
+    }
     for (;;) {
         if (s.top_pos < s.top_end) {
             int ord = (int)tt.titems[s.top_pos++];
-            if (ord < sc.n_squares) {
-                const float4* q = tt.squares + 4 * ord;
-                float t, u, v;
-                if (square_test(s.r, q[0], q[1], q[2], q[3], t, u, v) && t <= s.bound) { shadow_on_hit(sc, s, cnt); if (s.st == ST_IDLE) return; }
-            } else if (ord < sc.n_squares + sc.n_spheres) {
-                const float4* q = tt.spheres + 2 * (ord - sc.n_squares);
-                float t; F3 n;
-                if (sphere_test(s.r, q[0], t, n) && t <= s.bound) { shadow_on_hit(sc, s, cnt); if (s.st == ST_IDLE) return; }
-            } else {
-                DMesh m = tt.meshes[ord - sc.n_squares - sc.n_spheres];
-                /* beyond(): (tEnter - slack)*0.99999 > bound; the slightly weaker tEnter - slack > bound*1.00002 is
-                 * still conservative and costs one compare per child */
-                s.prune_t = (s.ts & TS_MODE) == 0u ? s.bound * 1.00002f : INFINITY;
-                s.prune_raw = s.prune_t;
-                if (QUANT) s.prune_t = fminf(100.0f, s.prune_t);     /* tMax of AABB::intersect */
-                else s.maxinv = max_abs_inv(s.r);
-                s.link = QUANT ? m.wroot : m.root; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
-                if (QUANT) {
-                    quant_setup(s.q, s.r, m);
-                    /* The reference tests no box for the mesh as a whole (Mesh.cpp:97-123 starts at the root's
-                     * children), but every box of the shadow tree lies inside the mesh's plane frame: a ray that
-                     * misses the whole frame (or reaches it beyond the distance of interest) cannot reach a leaf,
-                     * and stays at the top level -- scenes with dozens of meshes are mostly such visits. */
-                    if (m.wroot >= 0) {
-                        bool hit;
-                        quant_entry(0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, s.q, (m.wroot & WIDE_UNPRUNED) ? 100.0f : s.prune_t, hit);
-                        if (!hit) continue;
-                    }
-                }
-                s.st = ST_MESH;
-                return;
-            }
+            if (shadow_top_item<QUANT, false>(sc, tt, s, ord, w, cnt)) return;
             continue;
         }
         if (s.ts & TS_OPEN) s.ts = (s.ts & ~TS_OPEN) + TS_VISITED_ONE;
@@ -856,9 +890,26 @@ RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane
             else s.tlink = LINK_NONE;
         } else {
             if ((s.ts & TS_MODE) && TS_VISITED(s.ts) >= TS_LIMIT(s.ts)) { shadow_finish(s, true, cnt); return; }
-            uint2 lf = tt.tleaves[-1 - s.tlink];
-            s.top_pos = lf.x; s.top_end = lf.x + lf.y; s.ts |= TS_OPEN;
+            const int leaf = -1 - s.tlink;
             s.tlink = LINK_NONE;
+            s.ts |= TS_OPEN;
+            if (TOPSUB) {
+                const int sub = tt.tsub[leaf];
+                /* the object boxes of the sub-tree assume an origin within the scene's neighbourhood (rtgpu.hip); NaN compares false */
+                const TopFrame* tf = tt.tf;
+                const bool inside = s.r.o.x >= tf->omin[0] && s.r.o.x <= tf->omax[0] && s.r.o.y >= tf->omin[1] && s.r.o.y <= tf->omax[1] &&
+                                    s.r.o.z >= tf->omin[2] && s.r.o.z <= tf->omax[2];
+                if (sub != LINK_NONE && inside) {
+                    s.top_pos = s.top_end = 0;
+                    s.prune_raw = (s.ts & TS_MODE) == 0u ? s.bound * 1.00002f : INFINITY;
+                    quant_setup(s.q, s.r, tf->frame);
+                    s.link = sub; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
+                    s.st = ST_MESH;
+                    return;
+                }
+            }
+            uint2 lf = tt.tleaves[leaf];
+            s.top_pos = lf.x; s.top_end = lf.x + lf.y;
         }
     }
 }
@@ -943,7 +994,6 @@ RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
 /* The 4-wide walk can have three links pending per level. Only the first lds_cap entries of a lane's stack
  * live in LDS (what keeps 16 waves on a CU); deeper ones -- rare -- go to a per-lane slice of global memory,
  * entry k of lane l of block b at ovf[(b*ovf_cap + k)*64 + l]. */
-struct WideStack { int* lds; int* ovf; int lds_cap; };
 RT_DEV void wpush(const WideStack& w, int& sp, int link) {
     if (sp < w.lds_cap) w.lds[sp * RT_BLOCK] = link; else w.ovf[(sp - w.lds_cap) * RT_BLOCK] = link;
     sp++;
@@ -954,7 +1004,7 @@ RT_DEV int wpop(const WideStack& w, int& sp) {
 }
 /* one 4-wide node (64 bytes: twelve packed plane pairs, four links): the nearest hit child next, the others pushed.
  * Stack traffic stays in LDS unless this step could cross lds_cap (then, and only then, the spilling push/pop run). */
-template <bool SUB>
+template <bool SUB, bool TOPSUB>
 RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& w) {
     int link = s.link;
     if (link == LINK_NONE) {                                         /* the one place where the walk pops */
@@ -962,6 +1012,15 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
         --s.msp;
         if (s.msp < w.lds_cap) link = w.lds[s.msp * RT_BLOCK];
         else { asm volatile("" ::: "memory"); link = w.ovf[(s.msp - w.lds_cap) * RT_BLOCK]; }   /* (kept a branch: a select of the two addresses becomes a flat load) */
+    }
+    if (TOPSUB && link == LINK_SENTINEL) {
+        /* the mesh entered from the sub-tree of a top-level leaf is done: back to the scene's frame -- once the mesh's
+         * last pending leaf has been tested (a fat leaf that passes its box pushes its own sub-tree, which belongs above
+         * the sentinel: until then the sentinel stays on the stack and the lane is blocked) */
+        if (s.tri_pos != TRI_NONE) { ++s.msp; s.link = LINK_NONE; s.st = ST_BLOCKED; return; }
+        quant_setup(s.q, s.r, w.tf->frame);
+        s.link = LINK_NONE;
+        return;
     }
     if (link >= 0) {
         /* the child boxes of this tree already hold every hit accepted below them (quantise_mesh), so a child entered
@@ -972,11 +1031,12 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
         if (SUB && (link & WIDE_SUB)) lim = (link & WIDE_UNPRUNED) ? INFINITY : s.prune_raw;
         const uint4* nd = sc.wnodes + 4 * (size_t)(link & WIDE_INDEX);
         uint4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+        const float lo = (TOPSUB && (link & WIDE_LINE)) ? -INFINITY : 0.0f;
         bool h0, h1, h2, h3;
-        float t0 = quant_entry(a.x, a.y, a.z, s.q, lim, h0);
-        float t1 = quant_entry(a.w, b.x, b.y, s.q, lim, h1);
-        float t2 = quant_entry(b.z, b.w, c.x, s.q, lim, h2);
-        float t3 = quant_entry(c.y, c.z, c.w, s.q, lim, h3);
+        float t0 = quant_entry(a.x, a.y, a.z, s.q, lim, h0, lo);
+        float t1 = quant_entry(a.w, b.x, b.y, s.q, lim, h1, lo);
+        float t2 = quant_entry(b.z, b.w, c.x, s.q, lim, h2, lo);
+        float t3 = quant_entry(c.y, c.z, c.w, s.q, lim, h3, lo);
         const int l0 = (int)d.x, l1 = (int)d.y, l2 = (int)d.z, l3 = (int)d.w;
         /* nearest hit child first (an occluder is usually found early that way); the order of the rest is free */
 #if RT_CHILD_ORDER == 0
@@ -1006,6 +1066,14 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
             }
             link = la;
         } else link = LINK_NONE;                                      /* nothing hit: the next step pops */
+    }
+    if (TOPSUB && link < 0 && link != LINK_NONE && (leaf_first(link) & TOP_ITEM)) {
+        /* an object of a top-level leaf (the walk is in the leaf's sub-tree; no triangle leaf can be pending there):
+         * the top-level step tests it, then this walk goes on */
+        s.tri_pos = leaf_first(link);
+        s.link = LINK_NONE;
+        s.st = ST_TOP;
+        return;
     }
     if (link < 0 && link != LINK_NONE && s.tri_pos == TRI_NONE) {
         s.tri_pos = leaf_first(link) | TRI_NEW;
@@ -1178,15 +1246,15 @@ __global__ void __launch_bounds__(RT_FBLOCK) k_shadow_front(DScene sc, FrameD fr
 
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
-template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves and batched top-level rounds. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
+template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves and batched top-level rounds, 3: ... and sub-trees over the objects of top-level leaves. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
                                                         uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds,
                                                         int* ovf, int lds_cap, int ovf_cap, int top_min, const unsigned long long* total_ptr) {
     constexpr bool count_steps = COUNT;
     if (total_ptr) total = *total_ptr;       /* the rays the front pass deferred (k_shadow_front) */
-    constexpr bool QUANT = MODE != 0, SUB = MODE == 2;
+    constexpr bool QUANT = MODE != 0, SUB = MODE >= 2, TOPSUB = MODE == 3;
     extern __shared__ __align__(16) int s_stack[];
-    unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0, c_wn = 0, c_wt = 0, c_wtop = 0, c_ltop = 0;
+    unsigned long long c_node = 0, c_tri = 0, c_other = 0, c_iter = 0, c_wn = 0, c_wt = 0, c_wtop = 0, c_ltop = 0, c_m1n = 0, c_m1t = 0;
     int* stk = s_stack + threadIdx.x;
     constexpr int stride = RT_BLOCK;        /* the host always launches RT_BLOCK-lane blocks */
     const int lane = __lane_id();
@@ -1209,6 +1277,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         tt.squares = reinterpret_cast<const float4*>(base + sc.top_off[3]);
         tt.spheres = reinterpret_cast<const float4*>(base + sc.top_off[4]);
         tt.meshes = reinterpret_cast<const DMesh*>(base + sc.top_off[5]);
+        tt.tf = reinterpret_cast<const TopFrame*>(base + sc.top_off[6]);
+        tt.tsub = reinterpret_cast<const int*>(base + sc.top_off[6] + sizeof(TopFrame));
+        wst.tf = tt.tf;
     }
     ShadowLane s;
     s.st = ST_IDLE;
@@ -1269,7 +1340,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const int ntop = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_TOP));
             top_round = ntop >= top_min || __builtin_amdgcn_ballot_w64(s.st >= ST_MESH) == 0ull;
         }
-        if (top_round && s.st == ST_TOP) shadow_advance_top<QUANT>(sc, tt, s, stk, stride, cnt);
+        if (top_round && s.st == ST_TOP) shadow_advance_top<QUANT, TOPSUB>(sc, tt, s, stk, stride, cnt, wst);
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_top += k_t1 - k_t0; k_t0 = k_t1; }
         /* node phase */
 #pragma unroll 1
@@ -1279,8 +1350,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const bool walking = s.st == ST_MESH, waiting = s.st == ST_BLOCKED;
             unsigned long long mw = __builtin_amdgcn_ballot_w64(walking), mt = __builtin_amdgcn_ballot_w64(waiting);
             if (mw == 0ull || __popcll(mw) < __popcll(mt)) break;
-            if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wn++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; } }
-            if (walking) { if (QUANT) shadow_quant_step<SUB>(sc, s, wst); else shadow_node_step(sc, s, stk, stride); }
+            if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wn++; if (walking) { if (s.link >= 0 || s.msp > sc.top_cap) c_node++; else c_other++; if (s.ts & TS_MODE) c_m1n++; } }
+            if (walking) { if (QUANT) shadow_quant_step<SUB, TOPSUB>(sc, s, wst); else shadow_node_step(sc, s, stk, stride); }
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_nodeph += k_t1 - k_t0; k_t0 = k_t1; }
         /* triangle phase: worth a round once enough lanes have a leaf pending, or when the walkers are the minority */
@@ -1296,7 +1367,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const int np = __popcll(__builtin_amdgcn_ballot_w64(pending));
             if (np == 0) break;
             if (k > 0 && np < RT_TRI_MORE && __builtin_amdgcn_ballot_w64(s.st == ST_MESH) != 0ull) break;   /* a thin follow-up round only if nobody could walk instead */
-            if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wt++; if (pending) c_tri++; }
+            if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wt++; if (pending) { c_tri++; if (s.ts & TS_MODE) c_m1t++; } }
             if (pending) { if (QUANT) shadow_quant_tri_step<SUB>(sc, s, cnt, wst); else shadow_tri_step(sc, s, cnt); }
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_triph += k_t1 - k_t0; }
@@ -1305,7 +1376,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     if (count_steps) {
         atomicAdd(&ctr->sh_node_steps, c_node); atomicAdd(&ctr->sh_tri_steps, c_tri);
         atomicAdd(&ctr->sh_other_steps, c_other); atomicAdd(&ctr->sh_loop_iters, c_iter);
-        atomicAdd(&ctr->sh_top_lanes, c_ltop);
+        atomicAdd(&ctr->sh_top_lanes, c_ltop); atomicAdd(&ctr->sh_m1_node, c_m1n); atomicAdd(&ctr->sh_m1_tri, c_m1t);
         if (threadIdx.x == 0) { atomicAdd(&ctr->sh_clk_refill, k_refill); atomicAdd(&ctr->sh_clk_top, k_top); atomicAdd(&ctr->sh_clk_node, k_nodeph); atomicAdd(&ctr->sh_clk_tri, k_triph); }
         if (threadIdx.x == 0) { atomicAdd(&ctr->sh_node_iters, c_wn); atomicAdd(&ctr->sh_tri_iters, c_wt); atomicAdd(&ctr->sh_top_iters, c_wtop); }
     }

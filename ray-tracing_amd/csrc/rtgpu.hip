@@ -425,7 +425,8 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                                        w.ovf, lds_cap, ovf_cap, top_min,
                                        front ? static_cast<const unsigned long long*>(&d_ctr->deferred) : static_cast<const unsigned long long*>(nullptr));
                 };
-                if (c->sc.quant_ok && (c->sc.has_sub || top_min > 1)) { if (c->count_steps) launch(k_shadow<2, true>); else launch(k_shadow<2, false>); }
+                if (c->sc.quant_ok && c->sc.has_topsub) { if (c->count_steps) launch(k_shadow<3, true>); else launch(k_shadow<3, false>); }
+                else if (c->sc.quant_ok && (c->sc.has_sub || top_min > 1)) { if (c->count_steps) launch(k_shadow<2, true>); else launch(k_shadow<2, false>); }
                 else if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<1, true>); else launch(k_shadow<1, false>); }
                 else { if (c->count_steps) launch(k_shadow<0, true>); else launch(k_shadow<0, false>); }
                 if (e2) HIP_TRY(c, hipEventRecord(e2->b, c->stream));
@@ -454,8 +455,8 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                 c->h_ctr->sh_node_steps, c->h_ctr->sh_tri_steps, c->h_ctr->sh_other_steps, c->h_ctr->sh_loop_iters, c->h_ctr->rays_shadow,
                 c->h_ctr->sh_node_iters, c->h_ctr->sh_tri_iters, c->h_ctr->sh_top_iters, c->h_ctr->sh_top_lanes);
     if (c->count_steps)
-        fprintf(stderr, "[rtgpu] shadow wave clocks: refill %llu top %llu node phase %llu triangle phase %llu\n", c->h_ctr->sh_clk_refill,
-                c->h_ctr->sh_clk_top, c->h_ctr->sh_clk_node, c->h_ctr->sh_clk_tri);
+        fprintf(stderr, "[rtgpu] shadow wave clocks: refill %llu top %llu node phase %llu triangle phase %llu; in mode 1: node steps %llu tri steps %llu\n", c->h_ctr->sh_clk_refill,
+                c->h_ctr->sh_clk_top, c->h_ctr->sh_clk_node, c->h_ctr->sh_clk_tri, c->h_ctr->sh_m1_node, c->h_ctr->sh_m1_tri);
     for (size_t i = 0; i < c->ev_used; i++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) {
@@ -531,6 +532,9 @@ struct HitBox {
 #endif
 #ifndef RT_SUB_RUN
 #define RT_SUB_RUN 2             /* triangles per run (sub-tree leaf) */
+#endif
+#ifndef RT_TOP_SPLIT
+#define RT_TOP_SPLIT 4           /* top-level leaves with more objects than this get a sub-tree over their objects */
 #endif
 struct SubNode { HitBox box[2]; int32_t link[2]; };     /* link >= 0: index into the sub-node array; < 0: a run, -2 - (first record | TRI_SUB) */
 struct LeafSplitter {
@@ -1010,6 +1014,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     std::vector<uint8_t> qunp((size_t)d->n_mesh_nodes * 2, 0);
     std::vector<float> texc;
     std::vector<SubNode> subs;                                              /* sub-trees of fat leaves, all meshes */
+    std::vector<HitBox> mesh_hit((size_t)d->n_meshes);                      /* per mesh: what every accepted hit on it stays inside */
     /* the sub-tree variants of the kernels cost a few per cent where no leaf is fat, so a handful of fat leaves
      * (C5 has five among millions) is not worth them: at least RT_SPLIT_SHARE of the triangles must sit in fat leaves */
     bool split_leaves = false;
@@ -1020,7 +1025,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
         if (getenv("RT_FORCE_LEAF_SPLIT")) split_leaves = fat > 0;       /* test knob */
     }
     bool quant_ok = true;
-    int max_mesh_depth = 0, max_wide_depth = 0, max_sub_depth = 0, max_wide_sub_depth = 0;
+    int max_mesh_depth = 0, max_wide_depth = 0, max_sub_depth = 0, max_wide_sub_depth = 0, max_wide_top_depth = 0;
     for (int mi = 0; mi < d->n_meshes; mi++) {
         const rt_mesh& m = d->meshes[mi];
         max_mesh_depth = std::max(max_mesh_depth, m.depth);
@@ -1154,7 +1159,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
             return b;
         };
         float worst = 0.f;
-        if (meshes[mi].root >= 0) below(meshes[mi].root);
+        mesh_hit[(size_t)mi] = below(meshes[mi].root);          /* (fills hbox on the way) */
         for (int64_t i = 0; i < m.node_count; i++) {       /* the exact walks prune in time: how far the hits leave the reference box */
             rt_bvh_node& n = nodes[(size_t)(m.node_first + i)];
             const float* mn[2] = {n.lmin, n.rmin};
@@ -1193,7 +1198,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
         }
     }
     if (d->n_verts > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "too many vertices");
-    if (wnodes.size() / 4 >= (size_t)WIDE_SUB) return fail(c, RT_ERR_LIMIT, "too many mesh nodes");
+    if (wnodes.size() / 4 + 4096 >= (size_t)WIDE_INDEX) return fail(c, RT_ERR_LIMIT, "too many mesh nodes");
     if (c->debug) {
         size_t unb = 0;
         float worst = 0.f;
@@ -1277,6 +1282,201 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     for (int i = 0; i < d->n_top_leaves; i++) tleaves[i] = make_uint2(d->top_leaves[i].first, d->top_leaves[i].count);
     std::vector<uint32_t> titems(d->top_items, d->top_items + d->n_top_items);
 
+    /* ---- sub-trees inside top-level leaves. A shadow query asks, per top-level leaf the reference reaches, whether SOME object
+     * of the leaf is hit (at t <= lightDistance / at all, rt_kernels.h shadow_walk), so the order in which the objects of a
+     * leaf are looked at is free, and an object the ray cannot hit need not be looked at. The reference's depth-3 top-level tree
+     * leaves up to 22 objects in a leaf (default scene: 84 objects in 8 leaves), which the walk used to test one after the
+     * other. A leaf of more than RT_TOP_SPLIT objects gets a small SAH tree over conservative boxes of its objects (what
+     * every accepted hit on the object stays inside), in the same 4-wide quantised node format as the mesh shadow trees
+     * (planes in the frame of the whole scene), hung behind the leaf: the walk opens the leaf as before (reachability and
+     * the order of the leaves are the reference's), then walks this tree and tests only the objects whose box it enters. */
+    std::vector<int32_t> tsub((size_t)std::max(d->n_top_leaves, 1), LINK_NONE);
+    DMesh top_frame{};
+    float top_omin[3] = {0.f, 0.f, 0.f}, top_omax[3] = {0.f, 0.f, 0.f};
+    int max_top_sub_depth = 0;
+    bool has_topsub = false;
+    if (quant_ok && !getenv("RT_NO_TOP_SPLIT") && d->n_top_items > 0) {
+        const int n_obj = d->n_squares + d->n_spheres + d->n_meshes;
+        /* the scene's extent (object boxes without padding) bounds where shadow rays start: origins further out than one
+         * diagonal take the plain item scan (checked per ray in the kernel) */
+        double emin[3] = {INFINITY, INFINITY, INFINITY}, emax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        auto grow = [&](const double* lo, const double* hi) { for (int k = 0; k < 3; k++) { emin[k] = std::min(emin[k], lo[k]); emax[k] = std::max(emax[k], hi[k]); } };
+        bool finite = true;
+        for (int i = 0; i < d->n_squares && finite; i++) {
+            const rt_square& q = d->squares[i];
+            double lo[3], hi[3];
+            for (int k = 0; k < 3; k++) {
+                const double v4 = (double)q.v1[k] + (double)q.v3[k] - (double)q.v0[k];
+                lo[k] = std::min(std::min((double)q.v0[k], (double)q.v1[k]), std::min((double)q.v3[k], v4));
+                hi[k] = std::max(std::max((double)q.v0[k], (double)q.v1[k]), std::max((double)q.v3[k], v4));
+                if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false;
+            }
+            if (finite) grow(lo, hi);
+        }
+        for (int i = 0; i < d->n_spheres && finite; i++) {
+            const rt_sphere& sp = d->spheres[i];
+            double lo[3], hi[3];
+            if (!(sp.radius > 0.f) || !(sp.radius < 1e15f)) { finite = false; break; }
+            for (int k = 0; k < 3; k++) { lo[k] = (double)sp.center[k] - sp.radius; hi[k] = (double)sp.center[k] + sp.radius; if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false; }
+            if (finite) grow(lo, hi);
+        }
+        for (int mi = 0; mi < d->n_meshes && finite; mi++) {
+            const HitBox& hb = mesh_hit[(size_t)mi];
+            if (hb.unbounded) { finite = false; break; }
+            if (!(hb.mn[0] <= hb.mx[0])) continue;            /* a mesh that cannot be hit */
+            double lo[3], hi[3];
+            for (int k = 0; k < 3; k++) { lo[k] = hb.mn[k]; hi[k] = hb.mx[k]; if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false; }
+            if (finite) grow(lo, hi);
+        }
+        const double diag = finite && emin[0] <= emax[0] ? std::sqrt((emax[0] - emin[0]) * (emax[0] - emin[0]) + (emax[1] - emin[1]) * (emax[1] - emin[1]) + (emax[2] - emin[2]) * (emax[2] - emin[2])) : 0.0;
+        if (finite && diag > 0.0 && diag < 1e12) {
+            /* conservative box per object ordinal */
+            std::vector<HitBox> obox((size_t)n_obj);
+            const double u = 1.0 / 16777216.0;
+            double amax_scene = 0.0;
+            for (int k = 0; k < 3; k++) amax_scene = std::max(amax_scene, std::max(std::fabs(emin[k] - diag), std::fabs(emax[k] + diag)));
+            const double Dmax = 2.5 * diag;            /* largest distance between an admitted origin and a point of the scene */
+            for (int i = 0; i < d->n_squares; i++) {
+                /* Square::intersect accepts P = o + t*d (t > 0) whose u, v computed FROM P lie in [0, 1] (Square.h:81-89): P is
+                 * inside the quad up to the rounding of those dot products and off its plane by the rounding of t */
+                const rt_square& q = d->squares[i];
+                HitBox& b = obox[(size_t)i];
+                double ext = 0.0;
+                for (int k = 0; k < 3; k++) ext = std::max(ext, std::max(std::fabs((double)q.v1[k] - q.v0[k]), std::fabs((double)q.v3[k] - q.v0[k])));
+                const float pad = (float)(1e-4 * ext + 64.0 * u * (amax_scene + Dmax) + 1e-6);
+                for (int k = 0; k < 3; k++) {
+                    const float v4 = q.v1[k] + q.v3[k] - q.v0[k];
+                    b.mn[k] = std::min(std::min(q.v0[k], q.v1[k]), std::min(q.v3[k], v4)) - pad;
+                    b.mx[k] = std::max(std::max(q.v0[k], q.v1[k]), std::max(q.v3[k], v4)) + pad;
+                }
+            }
+            for (int i = 0; i < d->n_spheres; i++) {
+                /* Sphere::intersect (Sphere.h:86-146) accepts P = o + t*d for a float root t of a*t^2 + b*t + c: with the
+                 * coefficients and the root rounded, | |P - centre|^2 - r^2 | <= 96 u (|o - centre| + r)^2, hence P lies within
+                 * 96 u (D + r)^2 / r of the sphere (D: the largest admitted distance of an origin). The root may be NEGATIVE
+                 * (discriminant exactly 0, Sphere.h:113): nodes holding a sphere are tested against the ray's whole line (WIDE_LINE). */
+                const rt_sphere& sp = d->spheres[i];
+                HitBox& b = obox[(size_t)(d->n_squares + i)];
+                const double r = sp.radius;
+                const float pad = (float)(96.0 * u * (Dmax + r) * (Dmax + r) / r + 1e-5 * r + 64.0 * u * (amax_scene + Dmax) + 1e-6);
+                for (int k = 0; k < 3; k++) { b.mn[k] = sp.center[k] - sp.radius - pad; b.mx[k] = sp.center[k] + sp.radius + pad; }
+            }
+            for (int mi = 0; mi < d->n_meshes; mi++) obox[(size_t)(d->n_squares + d->n_spheres + mi)] = mesh_hit[(size_t)mi];
+            /* frame of the 16-bit planes: everything the boxes cover */
+            double gmin[3] = {INFINITY, INFINITY, INFINITY}, gmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (const HitBox& b : obox)
+                if (b.mn[0] <= b.mx[0]) for (int k = 0; k < 3; k++) { gmin[k] = std::min(gmin[k], (double)b.mn[k]); gmax[k] = std::max(gmax[k], (double)b.mx[k]); }
+            float fqmin[3], fqstep[3];
+            for (int k = 0; k < 3; k++) {
+                double step = std::max((gmax[k] - gmin[k]) / 65000.0, 1e-30);
+                fqstep[k] = (float)step;
+                if (!(fqstep[k] > 0.f)) fqstep[k] = 1e-30f;
+                fqmin[k] = (float)(gmin[k] - 8.0 * (double)fqstep[k]);
+                top_frame.qmin[k] = fqmin[k]; top_frame.qstep[k] = fqstep[k];
+                top_omin[k] = (float)(emin[k] - diag); top_omax[k] = (float)(emax[k] + diag);
+            }
+            top_frame.amax = (float)amax_scene;
+            top_frame.root = LINK_NONE; top_frame.wroot = LINK_NONE;
+            bool qok = true;
+            auto lo_q = [&](float v, int k) -> uint32_t {
+                double q = std::floor(((double)v - (double)fqmin[k]) / (double)fqstep[k]) - 1.0;
+                if (!(q >= 0.0)) { if (!(q > -4.0)) qok = false; q = 0.0; }
+                if (q > 65535.0) { qok = false; q = 65535.0; }
+                return (uint32_t)q;
+            };
+            auto hi_q = [&](float v, int k) -> uint32_t {
+                double q = std::ceil(((double)v - (double)fqmin[k]) / (double)fqstep[k]) + 1.0;
+                if (!(q <= 65535.0)) { qok = false; q = 65535.0; }
+                if (q < 0.0) { qok = false; q = 0.0; }
+                return (uint32_t)q;
+            };
+            /* binary SAH trees over the items of the fat top-level leaves, as 32-byte quantised nodes behind the mesh nodes */
+            struct TopNode { HitBox box[2]; int32_t link[2]; };
+            std::vector<TopNode> tn;
+            std::function<int32_t(std::vector<int>&, int, int, HitBox&, int, int&)> build = [&](std::vector<int>& ord, int lo, int hi, HitBox& out, int level, int& depth) -> int32_t {
+                out = HitBox();
+                for (int i = lo; i < hi; i++) out.add(obox[(size_t)ord[(size_t)i]]);
+                if (hi - lo == 1) return (int32_t)(-2 - (int64_t)(TOP_ITEM | (uint32_t)ord[(size_t)lo]));
+                depth = std::max(depth, level + 1);
+                /* exhaustive sweep SAH: the lists are short (tens of objects) */
+                double best = INFINITY;
+                int best_axis = 0, best_mid = (lo + hi) / 2;
+                std::vector<int> tmp(ord.begin() + lo, ord.begin() + hi);
+                for (int k = 0; k < 3; k++) {
+                    std::stable_sort(tmp.begin(), tmp.end(), [&](int a, int b) { return obox[(size_t)a].mn[k] + obox[(size_t)a].mx[k] < obox[(size_t)b].mn[k] + obox[(size_t)b].mx[k]; });
+                    const int n = (int)tmp.size();
+                    std::vector<double> right((size_t)n + 1, 0.0);
+                    HitBox acc;
+                    for (int i = n - 1; i >= 1; i--) { acc.add(obox[(size_t)tmp[(size_t)i]]); right[(size_t)i] = LeafSplitter::half_area(acc) * (n - i); }
+                    acc = HitBox();
+                    for (int i = 1; i < n; i++) {
+                        acc.add(obox[(size_t)tmp[(size_t)i - 1]]);
+                        const double cost = LeafSplitter::half_area(acc) * i + right[(size_t)i];
+                        if (cost < best) { best = cost; best_axis = k; best_mid = lo + i; }
+                    }
+                }
+                {
+                    const int k = best_axis;
+                    std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int a, int b) { return obox[(size_t)a].mn[k] + obox[(size_t)a].mx[k] < obox[(size_t)b].mn[k] + obox[(size_t)b].mx[k]; });
+                }
+                const size_t me = tn.size();
+                tn.emplace_back();
+                HitBox bl, br;
+                const int32_t l = build(ord, lo, best_mid, bl, level + 1, depth), r = build(ord, best_mid, hi, br, level + 1, depth);
+                tn[me].box[0] = bl; tn[me].box[1] = br; tn[me].link[0] = l; tn[me].link[1] = r;
+                return (int32_t)me;
+            };
+            struct Pending { int leaf; int32_t root; bool line; };
+            std::vector<Pending> pend;
+            for (int li = 0; li < d->n_top_leaves; li++) {
+                const rt_bvh_leaf& lf = d->top_leaves[li];
+                if (lf.count <= (uint32_t)RT_TOP_SPLIT) continue;
+                std::vector<int> ord;
+                bool line = false, usable = true;
+                for (uint32_t i = 0; i < lf.count; i++) {
+                    const int o = (int)d->top_items[lf.first + i];
+                    const HitBox& b = obox[(size_t)o];
+                    if (b.unbounded) usable = false;
+                    if (!(b.mn[0] <= b.mx[0])) continue;          /* cannot be hit: not in the tree */
+                    if (o >= d->n_squares && o < d->n_squares + d->n_spheres) line = true;
+                    ord.push_back(o);
+                }
+                if (!usable || ord.size() < 2) continue;
+                HitBox all;
+                int depth = 0;
+                const int32_t root = build(ord, 0, (int)ord.size(), all, 0, depth);
+                max_top_sub_depth = std::max(max_top_sub_depth, depth);
+                pend.push_back({li, root, line});
+            }
+            if (!pend.empty()) {
+                const size_t base = qnodes.size() / 2;
+                qnodes.resize(2 * (base + tn.size()), make_uint4(0u, 0u, 0u, 0u));
+                qunp.resize(2 * (base + tn.size()), 0);
+                for (size_t i = 0; i < tn.size(); i++) {
+                    uint32_t w[6];
+                    int32_t link[2];
+                    for (int sd = 0; sd < 2; sd++) {
+                        const HitBox& hb = tn[i].box[sd];
+                        for (int k = 0; k < 3; k++) w[3 * sd + k] = lo_q(hb.mn[k], k) | (hi_q(hb.mx[k], k) << 16);
+                        link[sd] = tn[i].link[sd] >= 0 ? (int32_t)(base + (size_t)tn[i].link[sd]) : tn[i].link[sd];
+                    }
+                    qnodes[2 * (base + i)] = make_uint4(w[0], w[1], w[2], w[3]);
+                    qnodes[2 * (base + i) + 1] = make_uint4(w[4], w[5], (uint32_t)link[0], (uint32_t)link[1]);
+                }
+                if (qok) {
+                    WideFold wf{qnodes, (int32_t)(-2 - d->n_tris), fqstep, wnodes, qunp};
+                    for (const Pending& pe : pend) {
+                        wf.depth = 0;
+                        wf.link_flags = (int32_t)(WIDE_SUB | (pe.line ? WIDE_LINE : 0u));
+                        tsub[(size_t)pe.leaf] = wf.build((int32_t)(base + (size_t)pe.root), 0);
+                        max_wide_top_depth = std::max(max_wide_top_depth, wf.depth);
+                    }
+                    has_topsub = true;
+                }
+            }
+        }
+    }
+
     const rt_bvh_node* dn = nullptr;
     const rt_bvh_node* dtn = nullptr;
     if ((rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
@@ -1307,6 +1507,16 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
         section(squares.data(), squares.size() * sizeof(float4), 3);
         section(spheres.data(), spheres.size() * sizeof(float4), 4);
         section(meshes.data(), meshes.size() * sizeof(DMesh), 5);
+        {
+            static_assert(sizeof(TopFrame) % 16 == 0, "tsub follows the frame");
+            TopFrame tf{};
+            tf.frame = top_frame;
+            for (int k = 0; k < 3; k++) { tf.omin[k] = top_omin[k]; tf.omax[k] = top_omax[k]; }
+            std::vector<uint8_t> sec(sizeof(TopFrame) + tsub.size() * sizeof(int32_t));
+            memcpy(sec.data(), &tf, sizeof(TopFrame));
+            memcpy(sec.data() + sizeof(TopFrame), tsub.data(), tsub.size() * sizeof(int32_t));
+            section(sec.data(), sec.size(), 6);
+        }
         blob.resize((blob.size() + 15) & ~(size_t)15);
         const uint8_t* db = nullptr;
         if ((rc = upload(c, blob, &db))) { free_scene(c); return rc; }
@@ -1324,8 +1534,10 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     sc.top_cap = d->top_depth + 2;
     sc.stack_cap = sc.top_cap + max_mesh_depth + 2;
     sc.cstack_cap = sc.stack_cap + (subs.empty() ? 0 : 3 * max_wide_sub_depth + 5);
-    sc.wstack_cap = sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 3;
+    sc.wstack_cap = sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 3 + (has_topsub ? 3 * max_wide_top_depth + 2 : 0);
     sc.has_sub = subs.empty() ? 0 : 1;
+    sc.has_topsub = has_topsub ? 1 : 0;
+
     sc.quant_ok = (quant_ok && !getenv("RT_SHADOW_EXACT_NODES")) ? 1 : 0;
     {   /* The per-lane stacks of the walks live in LDS (4 bytes x entries x threads of the block; k_shadow's wide stack spills
          * beyond stack_cap). What a launch may ask for is a documented limit, not a launch failure at rt_flush: the one-wave
