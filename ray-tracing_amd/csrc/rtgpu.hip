@@ -418,6 +418,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                 if ((size_t)std::max<unsigned long long>(blocks, blocks_now) * ovf_cap * RT_BLOCK * sizeof(int) > w.ovf_bytes)
                     return fail(c, RT_ERR_LIMIT, "spill buffer of the shadow walk too small (%d entries per lane)", ovf_cap);
                 int top_min = c->sc.n_top_items >= 24 ? 32 : 1;       /* see k_shadow; measured on the default scene: 1, 8, 16, 32, 48, 60 -> 2365, 2205, 2065, 1828, 1839, 2111 ms */
+                if (c->sc.has_topsub) top_min = 1;                     /* (with sub-trees over the objects a top-level round is short: 32 / 16 / 8 / 1 -> 94.7 / 93.1 / 92.6 / 91.9 ms on the default scene at 4 spp) */
                 if (const char* e = getenv("RT_TOP_MIN")) top_min = std::max(1, atoi(e));
                 auto launch = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3((uint32_t)blocks_now), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, c->sc,

@@ -231,7 +231,8 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
     # fat leaves walked triangle by triangle (no sub-trees), and sub-trees in every leaf of more than 6 triangles
     # ... and top-level rounds of k_shadow that never wait / wait for 48 lanes, top-level tables read from global memory
     for knob, value in (("RT_NO_LEAF_SPLIT", "1"), ("RT_FORCE_LEAF_SPLIT", "1"), ("RT_TOP_MIN", "1"), ("RT_TOP_MIN", "48"),
-                        ("RT_TOP_GLOBAL", "1"), ("RT_FRONT", "1"), ("RT_FRONT", "0")):      # ... with and without the front pass
+                        ("RT_TOP_GLOBAL", "1"), ("RT_FRONT", "1"), ("RT_FRONT", "0"),       # ... with and without the front pass
+                        ("RT_NO_TOP_SPLIT", "1")):                                       # ... top-level leaves scanned object by object (no sub-trees over their objects)
         monkeypatch.setenv(knob, value)
         c5 = rt.Context(0)
         try:
