@@ -9,7 +9,7 @@
  * The reference has no FFI of its own; each entry point cites the
  * reference code it stands for. Plain pointers and sizes only; every function
  * returns 0 on success or a negative rt_status; no exception crosses the ABI.
- * A context is bound to ONE GPU (one process per GPU) and is not thread-safe.
+ * A context is not thread-safe (one host thread drives it; with several GPUs it starts a worker thread per device itself).
  */
 #ifndef RTGPU_H
 #define RTGPU_H
@@ -154,9 +154,16 @@ typedef struct {
     float u, v;
 } rt_hit;
 
-/* Creates a context on device_ids[0]. n_devices must be 1: scaling is one process per GPU
- * (tiles are sharded by the caller, frames gathered with RCCL outside this library). */
+/* Creates a context on the n_devices GPUs of device_ids (1 <= n_devices <= 64; the ThreadPool of main.cpp:204-205, as GPUs).
+ * One device: everything runs there. Several: the scene is replicated, rt_render_tile deals the tiles (round-robin along a
+ * tile row with a hashed offset per row), rt_flush drives every device from a host thread of its own, and the frame is
+ * gathered on device_ids[0] (packed tile slabs, hipMemcpyPeerAsync, scatter) -- rt_resolve_device's buffer lives there.
+ * The frame has the bits of a one-device render. rt_intersect / rt_occluded / rt_trace* run on device_ids[0].
+ * (Scaling across processes -- one process per GPU, RCCL -- is ray-tracing_amd/dist.py + bench.py.) */
 int rt_init(const int* device_ids, int n_devices, rt_ctx** out);
+/* Diagnostic, needs no GPU: which of n_devices gets the tile whose corner is (x0, y0) (32-pixel tile grid) -- the deal of
+ * rt_render_tile, the same rule as ray-tracing_amd/dist.py uses across processes. */
+int rt_tile_owner(int x0, int y0, int n_devices);
 void rt_shutdown(rt_ctx*);
 const char* rt_last_error(const rt_ctx*);
 

@@ -109,7 +109,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
                       ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", "<f4"), ("v", "<f4")])
 
 # every symbol include/rtgpu.h and include/rthost.h declare
-EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame",
+EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame",
            "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_get_stats",
            "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
@@ -134,6 +134,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.rt_init.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    L.rt_tile_owner.argtypes = [i32, i32, i32]
     L.rt_shutdown.argtypes = [vp]
     L.rt_shutdown.restype = None
     L.rt_last_error.argtypes = [vp]
@@ -346,15 +347,16 @@ def load_off(path):
 
 
 class Context:
-    """One GPU context (rt_ctx)."""
+    """A render context (rt_ctx) on one GPU, or on several (devices=[0, 1, ...]: tiles dealt inside the library)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
         self.L = lib()
         self.h = C.c_void_p()
-        ids = (C.c_int * 1)(device)
-        rc = self.L.rt_init(ids, 1, C.byref(self.h))
+        devs = [device] if devices is None else list(devices)
+        ids = (C.c_int * len(devs))(*devs)
+        rc = self.L.rt_init(ids, len(devs), C.byref(self.h))
         if rc != RT_OK:
-            raise RtError(f"rt_init(device={device}) failed ({rc}): no MI355X visible? (no CPU fallback)")
+            raise RtError(f"rt_init(devices={devs}) failed ({rc}): no MI355X visible? (no CPU fallback)")
         self.params = None
 
     def close(self):

@@ -79,6 +79,11 @@ struct rt_ctx {
     size_t ev_used = 0;
     hipEvent_t ev_frame_a = nullptr, ev_frame_b = nullptr;
     size_t lds_max = 65536;     /* sharedMemPerBlock of the device */
+    /* a context over several GPUs (rt_init with n_devices > 1): one full context per device; this one only deals the tiles
+     * and gathers the frame on subs[0]'s device */
+    std::vector<rt_ctx*> subs;
+    std::vector<std::vector<TileD>> sub_tiles;     /* per device: the tiles of this frame, `first` counted in PIXELS */
+    DevBuf mg_slab, mg_tiles;                      /* on subs[0]'s device: packed pixels / tile list of one other device */
     unsigned char* static_scratch = nullptr;   /* this device's copy of rt_static_scratch (rt_trace_static) */
 };
 
@@ -906,6 +911,49 @@ void free_scene(rt_ctx* c) {
 
 }  // namespace
 
+/* multi-GPU gather (rt_init with several devices): the pixels of a device's tiles, tile after tile, packed into a slab on the
+ * device that rendered them and scattered into the frame on the gathering device. `first` of a tile counts pixels here. */
+__global__ void __launch_bounds__(256) k_tiles_pack(const float* __restrict__ frame, int img_w, const TileD* tiles, int n_tiles, uint32_t n_pix, float* __restrict__ slab) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    FrameD one{}; one.spp = 1;
+    int x, y, s_;
+    locate_sample(tiles, n_tiles, one, i, x, y, s_);
+    const size_t at = ((size_t)y * img_w + x) * 3;
+    slab[3 * (size_t)i] = frame[at]; slab[3 * (size_t)i + 1] = frame[at + 1]; slab[3 * (size_t)i + 2] = frame[at + 2];
+}
+__global__ void __launch_bounds__(256) k_tiles_scatter(float* __restrict__ frame, int img_w, const TileD* tiles, int n_tiles, uint32_t n_pix, const float* __restrict__ slab) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    FrameD one{}; one.spp = 1;
+    int x, y, s_;
+    locate_sample(tiles, n_tiles, one, i, x, y, s_);
+    const size_t at = ((size_t)y * img_w + x) * 3;
+    frame[at] = slab[3 * (size_t)i]; frame[at + 1] = slab[3 * (size_t)i + 1]; frame[at + 2] = slab[3 * (size_t)i + 2];
+}
+
+namespace {
+/* the deal of tiles to devices: round-robin along a tile row with a hashed offset per row (the same rule as
+ * ray-tracing_amd/dist.py: cost per pixel is heavy-tailed, and 120 tiles per row over 2/4/8 devices must not become column stripes) */
+inline uint32_t tile_row_offset(uint32_t ty, uint32_t world) {
+    uint32_t h = ty * 0x9E3779B1u + 0x7F4A7C15u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h % world;
+}
+inline int tile_owner(int x0, int y0, int world) { return (int)(((uint32_t)(x0 / 32) + tile_row_offset((uint32_t)(y0 / 32), (uint32_t)world)) % (uint32_t)world); }
+
+template <typename F>
+int on_all(rt_ctx* c, F body) {           /* body(sub) on every device, one host thread each; the first error wins */
+    std::vector<int> rc(c->subs.size(), RT_OK);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < c->subs.size(); k++) th.emplace_back([&, k] { rc[k] = body(c->subs[k]); });
+    for (auto& t : th) t.join();
+    for (size_t k = 0; k < rc.size(); k++)
+        if (rc[k]) return fail(c, rc[k], "device %d: %s", c->subs[k]->device, c->subs[k]->err.c_str());
+    return RT_OK;
+}
+}  // namespace
+
 extern "C" {
 
 uint32_t rt_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code, uint32_t light, uint32_t i, uint32_t which) {
@@ -913,6 +961,8 @@ uint32_t rt_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code, u
 }
 
 const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rt_tile_owner(int x0, int y0, int n_devices) { return (n_devices < 1 || x0 < 0 || y0 < 0) ? RT_ERR_ARG : tile_owner(x0, y0, n_devices); }
 
 double rt_hit_excursion(const float v0[3], const float v1[3], const float v2[3], float amax) {
     const float s = 1.0001f;                                   /* the record of rt_upload_scene */
@@ -923,6 +973,7 @@ double rt_hit_excursion(const float v0[3], const float v1[3], const float v2[3],
 
 int rt_uses_quantised_shadow_nodes(const rt_ctx* c) {
     if (!c) return RT_ERR_ARG;
+    if (!c->subs.empty()) return rt_uses_quantised_shadow_nodes(c->subs[0]);
     if (!c->has_scene) return RT_ERR_STATE;
     return c->sc.quant_ok ? 1 : 0;
 }
@@ -930,7 +981,24 @@ int rt_uses_quantised_shadow_nodes(const rt_ctx* c) {
 int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
     if (!out) return RT_ERR_ARG;
     *out = nullptr;
-    if (n_devices != 1) return RT_ERR_ARG;      /* one process per GPU */
+    if (n_devices < 1 || n_devices > 64) return RT_ERR_ARG;
+    if (n_devices > 1) {
+        /* several GPUs behind one context: a full context per device (scene replicated), tiles dealt in rt_render_tile, every
+         * device driven by its own host thread in rt_flush, the frame gathered on device_ids[0] */
+        if (!device_ids) return RT_ERR_ARG;
+        rt_ctx* p = nullptr;
+        try { p = new rt_ctx(); } catch (...) { return RT_ERR_NOMEM; }
+        p->device = device_ids[0];
+        for (int k = 0; k < n_devices; k++) {
+            rt_ctx* sub = nullptr;
+            int rc = rt_init(device_ids + k, 1, &sub);
+            if (rc) { for (rt_ctx* q : p->subs) rt_shutdown(q); delete p; return rc; }
+            p->subs.push_back(sub);
+        }
+        p->sub_tiles.resize((size_t)n_devices);
+        *out = p;
+        return RT_OK;
+    }
     int dev = device_ids ? device_ids[0] : 0;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || dev < 0 || dev >= count) return RT_ERR_DEVICE;
@@ -967,6 +1035,13 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
 
 void rt_shutdown(rt_ctx* c) {
     if (!c) return;
+    if (!c->subs.empty()) {
+        (void)hipSetDevice(c->device);
+        release(c->mg_slab); release(c->mg_tiles);
+        for (rt_ctx* q : c->subs) rt_shutdown(q);
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
@@ -982,6 +1057,11 @@ void rt_shutdown(rt_ctx* c) {
 static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d);
 int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d) {
     if (!c || !d) return RT_ERR_ARG;
+    if (!c->subs.empty()) {
+        int rc = on_all(c, [&](rt_ctx* q) { return rt_upload_scene(q, d); });
+        c->has_scene = rc == RT_OK;
+        return rc;
+    }
     /* the host-side preparation sizes vectors by the caller's counts: no exception may cross the ABI */
     try { return upload_scene_impl(c, d); }
     catch (const std::bad_alloc&) { free_scene(c); return fail(c, RT_ERR_NOMEM, "out of host memory while preparing the scene"); }
@@ -1566,6 +1646,11 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
 
 int rt_set_camera(rt_ctx* c, const rt_camera* cam) {
     if (!c || !cam) return RT_ERR_ARG;
+    if (!c->subs.empty()) {
+        for (rt_ctx* q : c->subs) { int rc = rt_set_camera(q, cam); if (rc) return fail(c, rc, "%s", q->err.c_str()); }
+        c->has_camera = true;
+        return RT_OK;
+    }
     /* Camera::apply (Camera.cpp:125-132): I * T(x,y,z) * T(0,0,-zoom) * R, all glMultMatrix calls */
     double mv[16], t[16], r[16];
     m4_identity(mv);
@@ -1631,6 +1716,15 @@ static void set_frame(rt_ctx* c, const rt_render_params* p) {
 
 int rt_begin_frame(rt_ctx* c, const rt_render_params* p) {
     if (!c || !p) return RT_ERR_ARG;
+    if (!c->subs.empty()) {
+        int rc = on_all(c, [&](rt_ctx* q) { return rt_begin_frame(q, p); });
+        if (rc) return rc;
+        set_frame(c, p);
+        for (auto& t : c->sub_tiles) t.clear();
+        memset(&c->stats, 0, sizeof(c->stats));
+        c->has_frame = true;
+        return RT_OK;
+    }
     if (!c->has_scene) return fail(c, RT_ERR_STATE, "rt_begin_frame before rt_upload_scene");
     int rc = check_params(c, p);
     if (rc) return rc;
@@ -1653,6 +1747,20 @@ int rt_begin_frame(rt_ctx* c, const rt_render_params* p) {
 
 int rt_render_tile(rt_ctx* c, int x0, int y0, int w, int h) {
     if (!c) return RT_ERR_ARG;
+    if (!c->subs.empty()) {
+        if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_render_tile before rt_begin_frame");
+        const int k = tile_owner(std::max(x0, 0), std::max(y0, 0), (int)c->subs.size());
+        int rc = rt_render_tile(c->subs[(size_t)k], x0, y0, w, h);
+        if (rc) return fail(c, rc, "%s", c->subs[(size_t)k]->err.c_str());
+        if (w > 0 && h > 0) {
+            std::vector<TileD>& tl = c->sub_tiles[(size_t)k];
+            TileD t;
+            t.x0 = x0; t.y0 = y0; t.w = w; t.h = h;
+            t.first = tl.empty() ? 0ull : tl.back().first + (unsigned long long)tl.back().w * tl.back().h;
+            tl.push_back(t);
+        }
+        return RT_OK;
+    }
     if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_render_tile before rt_begin_frame");
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "rt_render_tile before rt_set_camera");
     if (w < 0 || h < 0 || x0 < 0 || y0 < 0 || x0 + w > c->fr.img_w || y0 + h > c->fr.img_h) return fail(c, RT_ERR_ARG, "tile outside the image");
@@ -1666,6 +1774,22 @@ int rt_render_tile(rt_ctx* c, int x0, int y0, int w, int h) {
 
 int rt_flush(rt_ctx* c) {
     if (!c) return RT_ERR_ARG;
+    if (!c->subs.empty()) {
+        if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_flush before rt_begin_frame");
+        int rc = on_all(c, [&](rt_ctx* q) { return rt_flush(q); });
+        if (rc) return rc;
+        /* statistics of the frame: counts add up, the devices ran side by side */
+        rt_stats t{};
+        for (rt_ctx* q : c->subs) {
+            const rt_stats& s = q->stats;
+            t.rays_primary += s.rays_primary; t.rays_secondary += s.rays_secondary; t.rays_shadow += s.rays_shadow; t.nonfinite += s.nonfinite;
+            t.iterations = std::max(t.iterations, s.iterations); t.peak_states = std::max(t.peak_states, s.peak_states);
+            t.ms_total = std::max(t.ms_total, s.ms_total); t.ms_closest += s.ms_closest; t.ms_shadow += s.ms_shadow;
+            t.launches_closest += s.launches_closest; t.launches_shadow += s.launches_shadow;
+        }
+        c->stats = t;
+        return RT_OK;
+    }
     if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_flush before rt_begin_frame");
     if (c->tiles.empty()) return RT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1697,6 +1821,44 @@ int rt_get_stats(rt_ctx* c, rt_stats* s) {
 
 int rt_resolve_device(rt_ctx* c, void* d_rgb) {
     if (!c || !d_rgb) return RT_ERR_ARG;
+    if (!c->subs.empty()) {
+        /* every device resolves its own frame (its tiles; the rest of it is never looked at); subs[0] resolves straight into
+         * the caller's buffer, the tiles of the others arrive as packed slabs (peer copy) and are scattered in */
+        int rc = rt_flush(c);
+        if (rc) return rc;
+        rt_ctx* d0 = c->subs[0];
+        if ((rc = rt_resolve_device(d0, d_rgb))) return fail(c, rc, "%s", d0->err.c_str());
+        rc = on_all(c, [&](rt_ctx* q) -> int {
+            if (q == d0) return RT_OK;
+            int r2 = rt_resolve_device(q, q->rgb.p);
+            return r2;
+        });
+        if (rc) return rc;
+        for (size_t k = 1; k < c->subs.size(); k++) {
+            rt_ctx* q = c->subs[k];
+            const std::vector<TileD>& tl = c->sub_tiles[k];
+            if (tl.empty()) continue;
+            const uint32_t n_pix = (uint32_t)(tl.back().first + (unsigned long long)tl.back().w * tl.back().h);
+            /* pack on the device that rendered */
+            HIP_TRY(c, hipSetDevice(q->device));
+            if ((rc = ensure(q, q->mg_slab, (size_t)n_pix * 12)) || (rc = ensure(q, q->mg_tiles, tl.size() * sizeof(TileD)))) return fail(c, rc, "%s", q->err.c_str());
+            HIP_TRY(c, hipMemcpyAsync(q->mg_tiles.p, tl.data(), tl.size() * sizeof(TileD), hipMemcpyHostToDevice, q->stream));
+            hipLaunchKernelGGL(k_tiles_pack, dim3((n_pix + 255) / 256), dim3(256), 0, q->stream, static_cast<const float*>(q->rgb.p), c->fr.img_w,
+                               static_cast<const TileD*>(q->mg_tiles.p), (int)tl.size(), n_pix, static_cast<float*>(q->mg_slab.p));
+            HIP_TRY(c, hipStreamSynchronize(q->stream));
+            /* move and scatter on the gathering device */
+            HIP_TRY(c, hipSetDevice(d0->device));
+            if ((rc = ensure(c, c->mg_slab, (size_t)n_pix * 12)) || (rc = ensure(c, c->mg_tiles, tl.size() * sizeof(TileD)))) return rc;
+            if (q->device == d0->device) HIP_TRY(c, hipMemcpyAsync(c->mg_slab.p, q->mg_slab.p, (size_t)n_pix * 12, hipMemcpyDeviceToDevice, d0->stream));
+            else HIP_TRY(c, hipMemcpyPeerAsync(c->mg_slab.p, d0->device, q->mg_slab.p, q->device, (size_t)n_pix * 12, d0->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->mg_tiles.p, tl.data(), tl.size() * sizeof(TileD), hipMemcpyHostToDevice, d0->stream));
+            hipLaunchKernelGGL(k_tiles_scatter, dim3((n_pix + 255) / 256), dim3(256), 0, d0->stream, static_cast<float*>(d_rgb), c->fr.img_w,
+                               static_cast<const TileD*>(c->mg_tiles.p), (int)tl.size(), n_pix, static_cast<const float*>(c->mg_slab.p));
+            HIP_TRY(c, hipStreamSynchronize(d0->stream));
+        }
+        HIP_TRY(c, hipGetLastError());
+        return RT_OK;
+    }
     int rc = rt_flush(c);
     if (rc) return rc;
     uint32_t npix = (uint32_t)((size_t)c->fr.img_w * c->fr.img_h);
@@ -1709,6 +1871,30 @@ int rt_resolve_device(rt_ctx* c, void* d_rgb) {
 
 int rt_download_framebuffer(rt_ctx* c, float* rgb, uint32_t* prim_id, rt_stats* stats) {
     if (!c || !rgb) return RT_ERR_ARG;
+    if (!c->subs.empty()) {
+        rt_ctx* d0 = c->subs[0];
+        if (!d0->rgb.p) return fail(c, RT_ERR_STATE, "rt_download_framebuffer before rt_begin_frame");
+        int rc = rt_resolve_device(c, d0->rgb.p);
+        if (rc) return rc;
+        const size_t npix = (size_t)c->fr.img_w * c->fr.img_h;
+        HIP_TRY(c, hipSetDevice(d0->device));
+        HIP_TRY(c, hipMemcpy(rgb, d0->rgb.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (prim_id) {
+            /* ids: every device's buffer holds its own tiles (0xFFFFFFFF elsewhere); merged on the host tile by tile */
+            std::vector<uint32_t> tmp(npix * 2);
+            HIP_TRY(c, hipMemcpy(prim_id, d0->prim.p, npix * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (size_t k = 1; k < c->subs.size(); k++) {
+                rt_ctx* q = c->subs[k];
+                HIP_TRY(c, hipSetDevice(q->device));
+                HIP_TRY(c, hipMemcpy(tmp.data(), q->prim.p, npix * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                for (const TileD& t : c->sub_tiles[k])
+                    for (int y = t.y0; y < t.y0 + t.h; y++)
+                        memcpy(prim_id + 2 * ((size_t)y * c->fr.img_w + t.x0), tmp.data() + 2 * ((size_t)y * c->fr.img_w + t.x0), (size_t)t.w * 2 * sizeof(uint32_t));
+            }
+        }
+        if (stats) *stats = c->stats;
+        return RT_OK;
+    }
     int rc = rt_resolve_device(c, c->rgb.p);
     if (rc) return rc;
     size_t npix = (size_t)c->fr.img_w * c->fr.img_h;
@@ -1727,6 +1913,7 @@ static int stage_in(rt_ctx* c, DevBuf& b, const void* host, size_t bytes) {
 }
 
 int rt_intersect(rt_ctx* c, const float* org, const float* dir, int64_t n, rt_hit* out) {
+    if (c && !c->subs.empty()) { int rc = rt_intersect(c->subs[0], org, dir, n, out); if (rc) c->err = c->subs[0]->err; return rc; }      /* explicit rays: the first device */
     if (!c || !org || !dir || !out || n < 0 || n > 0x7FFFFFFFll) return RT_ERR_ARG;
     if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
     if (n == 0) return RT_OK;
@@ -1751,6 +1938,7 @@ int rt_intersect(rt_ctx* c, const float* org, const float* dir, int64_t n, rt_hi
 }
 
 int rt_occluded(rt_ctx* c, const float* pts, const float* lp, int64_t n, int32_t* out) {
+    if (c && !c->subs.empty()) { int rc = rt_occluded(c->subs[0], pts, lp, n, out); if (rc) c->err = c->subs[0]->err; return rc; }      /* explicit rays: the first device */
     if (!c || !pts || !lp || !out || n < 0 || n > 0x7FFFFFFFll) return RT_ERR_ARG;
     if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
     if (n == 0) return RT_OK;
@@ -1772,6 +1960,7 @@ int rt_occluded(rt_ctx* c, const float* pts, const float* lp, int64_t n, int32_t
 
 int rt_trace(rt_ctx* c, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample, int64_t n,
              const rt_render_params* p, float* rgb) {
+    if (c && !c->subs.empty()) { int rc = rt_trace(c->subs[0], org, dir, pixel, sample, n, p, rgb); if (rc) c->err = c->subs[0]->err; return rc; }
     if (!c || !org || !dir || !pixel || !sample || !p || !rgb || n < 0 || n > 0x3FFFFFFFll) return RT_ERR_ARG;
     if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
     if (n == 0) return RT_OK;
@@ -1823,6 +2012,7 @@ int rt_trace(rt_ctx* c, const float* org, const float* dir, const uint32_t* pixe
  * counters; the per-batch queues are cleared by the loop) -- and calls that overlap on one GPU would race. */
 int rt_trace_static(rt_ctx* c, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample, int64_t n,
                     const rt_render_params* p, float* rgb) {
+    if (c && !c->subs.empty()) { int rc = rt_trace_static(c->subs[0], org, dir, pixel, sample, n, p, rgb); if (rc) c->err = c->subs[0]->err; return rc; }
     if (!c || !org || !dir || !pixel || !sample || !p || !rgb || n < 0) return RT_ERR_ARG;
     if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
     if (n > RT_STATIC_MAX_RAYS) return fail(c, RT_ERR_LIMIT, "rt_trace_static: %lld rays, the limit is %d", (long long)n, RT_STATIC_MAX_RAYS);
@@ -1905,6 +2095,7 @@ int rt_trace_static(rt_ctx* c, const float* org, const float* dir, const uint32_
 }
 
 int rt_camera_rays(rt_ctx* c, const rt_render_params* p, int x0, int y0, int w, int h, float* org, float* dir) {
+    if (c && !c->subs.empty()) { int rc = rt_camera_rays(c->subs[0], p, x0, y0, w, h, org, dir); if (rc) c->err = c->subs[0]->err; return rc; }      /* explicit rays: the first device */
     if (!c || !p || !org || !dir || w <= 0 || h <= 0) return RT_ERR_ARG;
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "no camera");
     int rc = check_params(c, p);

@@ -1,0 +1,48 @@
+"""Several GPUs behind ONE context (rt_init with n_devices > 1, include/rtgpu.h): tiles dealt inside the library, one host
+thread per device, frame gathered on the first device. The GPU box has one card, so the GPU test lists it twice -- two full
+sub-contexts with their own streams and scene copies on one device: every code path of the N-device case (deal, threads,
+pack, copy, scatter, id merge, statistics) except the peer copy itself, which degenerates to a device-to-device copy.
+N > 1 on N distinct cards is unmeasured."""
+import importlib
+
+import numpy as np
+import pytest
+
+rt = importlib.import_module("ray-tracing_amd")
+rtd = importlib.import_module("ray-tracing_amd.dist")
+
+
+def test_library_and_python_dealers_agree():
+    L = rt.lib()
+    for world in (1, 2, 3, 4, 8):
+        for ty in range(0, 70):
+            for tx in range(0, 121, 7):
+                assert L.rt_tile_owner(tx * 32, ty * 32, world) == rtd.tile_owner(tx, ty, world)
+    assert L.rt_tile_owner(0, 0, 0) < 0 and L.rt_tile_owner(-1, 0, 2) < 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,depth", [("mesh_gorilla", 50), ("final", 6)])
+def test_two_sub_contexts_give_the_one_device_frame(ctx, name, depth):
+    hs = rt.HostScene(name, 3, 12)
+    cam = rt.default_camera(100 / 72, zoom=25.0 if name == "final" else 3.0)
+    p = rt.make_params(100, 72, spp=2, max_depth=depth, light_samples=35, shadow_mode=0, jitter=1, seed=2)      # 72 rows, 100 columns: partial tiles on both edges
+    ctx.upload_scene(hs)
+    want, wprim, wst = ctx.render(cam, p)
+    multi = rt.Context(devices=[0, 0, 0])
+    try:
+        multi.upload_scene(hs)
+        got, gprim, gst = multi.render(cam, p)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(gprim, wprim)
+        assert (gst.rays_primary, gst.rays_secondary, gst.rays_shadow) == (wst.rays_primary, wst.rays_secondary, wst.rays_shadow)
+        # a second frame on the same context, fewer tiles: nothing of the first one may leak in
+        some = rt.interleaved_tiles(100, 72)[::3]
+        got2, _, _ = multi.render(cam, p, tiles=some)
+        want2, _, _ = ctx.render(cam, p, tiles=some)
+        assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+        # the seams on explicit rays run on the first device
+        org, dirs = multi.camera_rays(p, 10, 10, 8, 8)
+        assert np.array_equal(multi.intersect(org, dirs), ctx.intersect(org, dirs))
+    finally:
+        multi.close()
