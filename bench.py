@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--cpu-crop", type=int, default=256, help="side of the centred crop the CPU baseline renders (SURVEY 8(d): 256)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the C3/C4 frames")
+    ap.add_argument("--tree-mode", type=int, default=0, help="1: binned-SAH mesh tree (free topology: NOT the reference's answers, SURVEY 8(f).2); never the default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,7 +132,7 @@ def main():
     name = f"soup:{args.ntris}"
     key = f"{name}/d{args.mesh_depth}/{W}x{H}x{args.spp}"
     t0 = time.time()
-    scene = rt.HostScene(name, 3, args.mesh_depth)
+    scene = rt.HostScene(name, 3, args.mesh_depth, args.tree_mode)
     t_build = time.time() - t0
     ctx = rt.Context(local_rank)
     t0 = time.time()
@@ -196,7 +197,7 @@ def main():
         # ---- CPU baseline + per-ray algorithmic work, from the oracle (test infrastructure) ----
         cpu = None
         per_ray = (load_json(PER_RAY_FILE) or {}).get(key)
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and args.tree_mode == 0:
             import oracle_lib as O
             avail = len(os.sched_getaffinity(0))
             if os.environ.get("OMP_NUM_THREADS", "").isdigit():
@@ -255,7 +256,7 @@ def main():
                 bpr = algorithmic_bytes_per_ray(per_ray["shadow_nodes"], per_ray["shadow_tris"])
                 roof["reference_algorithm_bytes_per_ray"] = round(bpr, 1)
                 roof["reference_algorithm_equiv_GBps"] = round(bpr * rays_per_launch / avg_s / 1e9, 1)
-        cfg = {"workload": f"C5: synthetic {args.ntris}-triangle soup, {W}x{H}, {args.spp} spp, soft shadows "
+        cfg = {"tree_mode": args.tree_mode, "workload": f"C5: synthetic {args.ntris}-triangle soup, {W}x{H}, {args.spp} spp, soft shadows "
                            f"(35 samples/light), depth {args.depth}, mesh BVH depth {args.mesh_depth}, counter RNG",
                "tiles": "32x32, round-robin per tile row with a hashed row offset", "parallelism": f"tile-sharded x{world}",
                "gather": f"all-gather of packed tile slabs, {gather.bytes_sent_per_rank()} B per rank" if world > 1 else "none (one rank)",

@@ -93,7 +93,7 @@ public:
     void rotate_y(float angle);                         /* Mesh.h:159-165 */
     void rotate_z(float angle);                         /* Mesh.h:167-173 */
     void build_arrays() { recomputeNormals(); }         /* Mesh.h:119-125 (GL arrays not needed) */
-    void buildTree(unsigned nb_of_subdivide_tree);      /* Mesh.cpp:144-179 */
+    void buildTree(unsigned nb_of_subdivide_tree, int tree_mode = 0);      /* Mesh.cpp:144-179; tree_mode: Settings::tree_mode */
     AABB getBoundingBox() const { return triangleTree.rootBox; }   /* Mesh.cpp:181-183 */
     size_t triangleCount() const { return triangles.size() / 3; }
 };
@@ -119,7 +119,13 @@ struct Light {                /* Scene.h:20-34 */
     Vec3 pos;
     float radius = 0.f;
 };
-struct Settings { unsigned tree_subdivide = 12; };      /* Scene.h:37-39, main.cpp:116 */
+struct Settings {                                       /* Scene.h:37-39, main.cpp:116 */
+    unsigned tree_subdivide = 12;
+    /* not in the reference: 0 = the reference's spatial-median builder (AccelerationStruct.cpp:151-195), the default and the
+     * only mode with parity; 1 = binned-SAH builder with free topology (tree_subdivide is still the depth limit): a few grazing
+     * pixels may change their hit identity, see tests/test_sah_mode.py */
+    int tree_mode = 0;
+};
 
 /* Camera.h / Camera.cpp:24-38 */
 struct Camera {
@@ -187,7 +193,7 @@ void set_asset_dir(const std::string& dir);
 void set_image_dir(const std::string& dir);            /* stands for the reference's "assets/img/" */
 
 /* BVH_Node::buildBVH for triangles (AccelerationStruct.cpp:91-113,151-195). */
-void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out);
+void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out, int tree_mode = 0);   /* tree_mode 1: binned SAH, not the reference's tree */
 /* BVH_Node::buildBVH for objects (AccelerationStruct.cpp:115-148,197-243). */
 void buildBVH(const std::vector<AABB>& objectBoxes, int deepLimit, FlatTree& out);
 
@@ -217,6 +223,8 @@ int rth_add_sphere(rth_scene*, const float center[3], float radius, const rt_mat
 int rth_add_mesh(rth_scene*, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt, const rt_material*);
 /* Scene::applySettings (mesh trees) + BVH_Node::buildBVH (top level) + flatten. */
 int rth_build(rth_scene*, int top_depth, int mesh_depth);
+/* ... with Settings::tree_mode for the mesh trees (0 = the reference's builder, 1 = binned SAH with free topology: no parity) */
+int rth_build_mode(rth_scene*, int top_depth, int mesh_depth, int tree_mode);
 const rt_scene_desc* rth_scene_desc(rth_scene*);
 int rth_ray_trace_from_camera(rt_ctx*, rth_scene*, const rt_camera*, const rt_render_params*, const char* ppm_path, double* seconds);
 int rth_write_ppm(const char* path, const float* rgb, int w, int h);

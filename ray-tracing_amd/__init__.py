@@ -113,7 +113,7 @@ EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_uploa
            "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_get_stats",
            "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
-           "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_scene_desc",
+           "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_build_mode", "rth_scene_desc",
            "rth_ray_trace_from_camera", "rth_write_ppm", "rth_load_off", "rth_scene_save", "rth_scene_load"]
 
 _lib = None
@@ -171,6 +171,7 @@ def lib():
     L.rth_add_sphere.argtypes = [vp, vp, C.c_float, C.POINTER(Material)]
     L.rth_add_mesh.argtypes = [vp, vp, i64, vp, i64, C.POINTER(Material)]
     L.rth_build.argtypes = [vp, i32, i32]
+    L.rth_build_mode.argtypes = [vp, i32, i32, i32]
     L.rth_scene_desc.argtypes = [vp]
     L.rth_scene_desc.restype = C.POINTER(SceneDesc)
     L.rth_ray_trace_from_camera.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(RenderParams), C.c_char_p,
@@ -225,14 +226,14 @@ def interleaved_tiles(w, h, rank=0, world=1, tile=32):
 class HostScene:
     """Host-side Scene mirror (rthost.h): named setup_* scenes or free-form geometry."""
 
-    def __init__(self, name=None, top_depth=3, mesh_depth=12):
+    def __init__(self, name=None, top_depth=3, mesh_depth=12, tree_mode=0):
         self.L = lib()
         self.h = C.c_void_p(self.L.rth_scene_new())
         if name is not None:
             rc = self.L.rth_scene_setup(self.h, name.encode())
             if rc != RT_OK:
                 raise RtError(f"rth_scene_setup({name!r}) failed ({rc}); asset dir ok?")
-            self.build(top_depth, mesh_depth)
+            self.build(top_depth, mesh_depth, tree_mode)
 
     @classmethod
     def from_file(cls, path, top_depth=3, mesh_depth=12):
@@ -288,8 +289,9 @@ class HostScene:
         if rc != RT_OK:
             raise RtError(f"rth_add_mesh failed ({rc})")
 
-    def build(self, top_depth=3, mesh_depth=12):
-        rc = self.L.rth_build(self.h, top_depth, mesh_depth)
+    def build(self, top_depth=3, mesh_depth=12, tree_mode=0):
+        """tree_mode 0: the reference's tree builder (parity); 1: binned SAH, free topology (no parity)."""
+        rc = self.L.rth_build_mode(self.h, top_depth, mesh_depth, tree_mode)
         if rc != RT_OK:
             raise RtError(f"rth_build failed ({rc})")
 

@@ -152,7 +152,7 @@ void Mesh::scale(const Vec3& s) { apply_transformation_matrix(scaleMatrix(s)); }
 void Mesh::rotate_x(float angle) { apply_transformation_matrix(rotX(angle)); }
 void Mesh::rotate_y(float angle) { apply_transformation_matrix(rotY(angle)); }
 void Mesh::rotate_z(float angle) { apply_transformation_matrix(rotZ(angle)); }
-void Mesh::buildTree(unsigned nb) { buildBVH(positions, triangles, (int)nb, triangleTree); }
+void Mesh::buildTree(unsigned nb, int tree_mode) { buildBVH(positions, triangles, (int)nb, triangleTree, tree_mode); }
 
 /* ------------------------------------------------------------------ Square / Sphere */
 void Square::setQuad(const Vec3& bottomLeft, const Vec3& rightVector, const Vec3& upVector, float width, float height) {
@@ -235,8 +235,59 @@ static void storeBoxes(rt_bvh_node& n, const AABB& l, const AABB& r) {
     for (int k = 0; k < 3; k++) { n.lmin[k] = l.min[k]; n.lmax[k] = l.max[k]; n.rmin[k] = r.min[k]; n.rmax[k] = r.max[k]; }
 }
 
+/* Mode 2, NOT the reference's tree (a free-topology builder): binned surface-area heuristic over the
+ * centroids, 16 bins per axis, the cheapest of the 45 candidate planes; same record array, same flattened output, leaf
+ * when n <= 2. The render loop walks such a tree like any other, but which triangles a ray can REACH then differs from
+ * the reference's (a triangle is only found along its own box chain, and the records are the triangles scaled by
+ * 1.0001 with a tolerance on top), so hit identities may differ in a few grazing pixels: a non-parity mode, off by default. */
+static bool sahSplit(const BuildRec* a, size_t lo, size_t hi, int& axis_out, float& pivot_out) {
+    constexpr int NB = 16;
+    float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = lo; i < hi; i++)
+        for (int k = 0; k < 3; k++) { cmn[k] = std::min(cmn[k], a[i].c[k]); cmx[k] = std::max(cmx[k], a[i].c[k]); }
+    double best = INFINITY;
+    bool found = false;
+    for (int k = 0; k < 3; k++) {
+        const float ext = cmx[k] - cmn[k];
+        if (!(ext > 0.f) || !(ext < 1e30f)) continue;
+        float bmn[NB][3], bmx[NB][3];
+        size_t cnt[NB];
+        for (int b = 0; b < NB; b++) { cnt[b] = 0; for (int j = 0; j < 3; j++) { bmn[b][j] = INFINITY; bmx[b][j] = -INFINITY; } }
+        const float scale = (float)NB / ext;
+        for (size_t i = lo; i < hi; i++) {
+            int b = (int)((a[i].c[k] - cmn[k]) * scale);
+            b = std::min(std::max(b, 0), NB - 1);
+            cnt[b]++;
+            for (int j = 0; j < 3; j++) { bmn[b][j] = std::min(bmn[b][j], a[i].mn[j]); bmx[b][j] = std::max(bmx[b][j], a[i].mx[j]); }
+        }
+        auto area = [](const float* mn, const float* mx) {
+            if (!(mn[0] <= mx[0])) return 0.0;
+            const double x = (double)mx[0] - mn[0], y = (double)mx[1] - mn[1], z = (double)mx[2] - mn[2];
+            return x * y + y * z + z * x;
+        };
+        double rarea[NB]; size_t rcnt[NB];
+        float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        size_t n = 0;
+        for (int b = NB - 1; b >= 1; b--) {
+            for (int j = 0; j < 3; j++) { amn[j] = std::min(amn[j], bmn[b][j]); amx[j] = std::max(amx[j], bmx[b][j]); }
+            n += cnt[b];
+            rarea[b] = area(amn, amx); rcnt[b] = n;
+        }
+        for (int j = 0; j < 3; j++) { amn[j] = INFINITY; amx[j] = -INFINITY; }
+        n = 0;
+        for (int b = 0; b + 1 < NB; b++) {
+            for (int j = 0; j < 3; j++) { amn[j] = std::min(amn[j], bmn[b][j]); amx[j] = std::max(amx[j], bmx[b][j]); }
+            n += cnt[b];
+            if (n == 0 || rcnt[b + 1] == 0) continue;
+            const double cost = area(amn, amx) * (double)n + rarea[b + 1] * (double)rcnt[b + 1];
+            if (cost < best) { best = cost; axis_out = k; pivot_out = cmn[k] + ext * (float)(b + 1) / (float)NB; found = true; }
+        }
+    }
+    return found;
+}
+
 /* mode 0: triangle tree (longest axis, leaf when n<=1); mode 1: object tree (shared axis
- * counter, leaf when n<=2). Returns the link of the subtree. */
+ * counter, leaf when n<=2); mode 2: triangle tree by binned SAH (sahSplit). Returns the link of the subtree. */
 static int32_t buildNode(FlatTree& t, BuildRec* a, size_t lo, size_t hi, int deepLimit, const AABB& box, int mode,
                          int& axisCounter, int level) {
     const size_t n = hi - lo;
@@ -246,15 +297,31 @@ static int32_t buildNode(FlatTree& t, BuildRec* a, size_t lo, size_t hi, int dee
         return emitLeaf(t, a, lo, hi);
     }
     Vec3 diag = box.max - box.min;
-    int axis;
-    if (mode == 0) {
-        axis = diag[0] > std::max(diag[1], diag[2]) ? 0 : diag[1] > diag[2] ? 1 : 2;   /* AccelerationStruct.cpp:160 */
+    int axis = 0;
+    float pivot = 0.f;
+    if (mode == 2) {
+        if (!sahSplit(a, lo, hi, axis, pivot)) {                                       /* all centroids in one point: halve by index */
+            const size_t half = lo + n / 2;
+            const int32_t me2 = (int32_t)t.nodes.size();
+            t.nodes.emplace_back();
+            std::memset(&t.nodes[me2], 0, sizeof(rt_bvh_node));
+            AABB lb2 = unionBox(a, lo, half), rb2 = unionBox(a, half, hi);
+            const int32_t l2 = buildNode(t, a, lo, half, deepLimit - 1, lb2, mode, axisCounter, level + 1);
+            const int32_t r2 = buildNode(t, a, half, hi, deepLimit - 1, rb2, mode, axisCounter, level + 1);
+            storeBoxes(t.nodes[me2], lb2, rb2);
+            t.nodes[me2].left = l2; t.nodes[me2].right = r2;
+            return me2;
+        }
     } else {
-        axisCounter %= 3;                                                              /* AccelerationStruct.cpp:206 */
-        axis = axisCounter;
+        if (mode == 0) {
+            axis = diag[0] > std::max(diag[1], diag[2]) ? 0 : diag[1] > diag[2] ? 1 : 2;   /* AccelerationStruct.cpp:160 */
+        } else {
+            axisCounter %= 3;                                                              /* AccelerationStruct.cpp:206 */
+            axis = axisCounter;
+        }
+        Vec3 center = box.min + diag / 2.f;
+        pivot = center[axis];
     }
-    Vec3 center = box.min + diag / 2.f;
-    const float pivot = center[axis];
     size_t mid = split(a, lo, hi, [axis, pivot](const BuildRec& r) { return r.c[axis] < pivot; });
     if (mode == 1) axisCounter++;                                                      /* AccelerationStruct.cpp:222 */
     const int32_t me = (int32_t)t.nodes.size();
@@ -286,14 +353,15 @@ static void appendFragment(FlatTree& t, const FlatTree& f, int32_t& link) {
     t.depth = std::max(t.depth, f.depth);
     link = moved(link);
 }
-static int32_t buildNodeParallel(FlatTree& t, BuildRec* a, size_t lo, size_t hi, int deepLimit, const AABB& box, int level, int threadsLeft) {
+static int32_t buildNodeParallel(FlatTree& t, BuildRec* a, size_t lo, size_t hi, int deepLimit, const AABB& box, int level, int threadsLeft, int mode = 0) {
     const size_t n = hi - lo;
     int unused = 0;
-    if (threadsLeft <= 1 || n < 200000 || !(deepLimit > 0 && n > 1)) return buildNode(t, a, lo, hi, deepLimit, box, 0, unused, level);
+    if (threadsLeft <= 1 || n < 200000 || !(deepLimit > 0 && n > 1)) return buildNode(t, a, lo, hi, deepLimit, box, mode, unused, level);
     Vec3 diag = box.max - box.min;
-    const int axis = diag[0] > std::max(diag[1], diag[2]) ? 0 : diag[1] > diag[2] ? 1 : 2;       /* AccelerationStruct.cpp:160 */
+    int axis = diag[0] > std::max(diag[1], diag[2]) ? 0 : diag[1] > diag[2] ? 1 : 2;       /* AccelerationStruct.cpp:160 */
     Vec3 center = box.min + diag / 2.f;
-    const float pivot = center[axis];
+    float pivot = center[axis];
+    if (mode == 2 && !sahSplit(a, lo, hi, axis, pivot)) return buildNode(t, a, lo, hi, deepLimit, box, mode, unused, level);
     const size_t mid = split(a, lo, hi, [axis, pivot](const BuildRec& r) { return r.c[axis] < pivot; });
     const int32_t me = (int32_t)t.nodes.size();
     t.nodes.emplace_back();
@@ -306,10 +374,10 @@ static int32_t buildNodeParallel(FlatTree& t, BuildRec* a, size_t lo, size_t hi,
     }
     int32_t l = 0, r = 0;
     std::thread left([&] {
-        if (mid - lo >= 1) { lb = unionBox(a, lo, mid); l = buildNodeParallel(lf, a, lo, mid, deepLimit - 1, lb, level + 1, threadsLeft / 2); }
+        if (mid - lo >= 1) { lb = unionBox(a, lo, mid); l = buildNodeParallel(lf, a, lo, mid, deepLimit - 1, lb, level + 1, threadsLeft / 2, mode); }
         else { int u = 0; l = buildNode(lf, a, lo, lo, 0, lb, 0, u, level + 1); }
     });
-    if (hi - mid >= 1) { rb = unionBox(a, mid, hi); r = buildNodeParallel(rf, a, mid, hi, deepLimit - 1, rb, level + 1, threadsLeft - threadsLeft / 2); }
+    if (hi - mid >= 1) { rb = unionBox(a, mid, hi); r = buildNodeParallel(rf, a, mid, hi, deepLimit - 1, rb, level + 1, threadsLeft - threadsLeft / 2, mode); }
     else { int u = 0; r = buildNode(rf, a, mid, mid, 0, rb, 0, u, level + 1); }
     left.join();
     appendFragment(t, lf, l);
@@ -320,7 +388,7 @@ static int32_t buildNodeParallel(FlatTree& t, BuildRec* a, size_t lo, size_t hi,
     return me;
 }
 
-void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out) {
+void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out, int tree_mode) {
     out = FlatTree();
     const size_t nt = triangles.size() / 3;
     std::vector<BuildRec> recs(nt);
@@ -348,7 +416,7 @@ void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& t
     const auto T0 = std::chrono::steady_clock::now();
     int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     if (const char* e = getenv("OMP_NUM_THREADS")) threads = std::max(1, std::min(threads, atoi(e)));
-    out.root = buildNodeParallel(out, recs.data(), 0, nt, deepLimit, box, 0, threads);
+    out.root = buildNodeParallel(out, recs.data(), 0, nt, deepLimit, box, 0, threads, tree_mode == 1 ? 2 : 0);
     if (getenv("RTH_TIMING")) fprintf(stderr, "[rthost] tree of %zu triangles, depth limit %d, %d threads: %.3f s\n", nt, deepLimit, threads, std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
 }
 
@@ -387,7 +455,7 @@ int Scene::addImage(int width, int height, int channels, const uint8_t* texels) 
     textures.push_back(std::move(img));
     return (int)textures.size() - 1;
 }
-void Scene::applySettings(Settings set) { for (Mesh& m : meshes) m.buildTree(set.tree_subdivide); }
+void Scene::applySettings(Settings set) { for (Mesh& m : meshes) m.buildTree(set.tree_subdivide, set.tree_mode); }
 void Scene::buildSceneBvh() {
     std::vector<AABB> boxes;                      /* squares, spheres, meshes: AccelerationStruct.cpp:123-134 */
     for (const Square& s : squares) boxes.push_back(s.getBoundingBox());
@@ -1025,11 +1093,13 @@ int rth_add_mesh(rth_scene* s, const float* verts, int64_t nv, const uint32_t* t
         return (int)RT_OK;
     });
 }
-int rth_build(rth_scene* s, int top_depth, int mesh_depth) {
-    if (!s || top_depth < 0 || mesh_depth < 0) return RT_ERR_ARG;
+int rth_build(rth_scene* s, int top_depth, int mesh_depth) { return rth_build_mode(s, top_depth, mesh_depth, 0); }
+int rth_build_mode(rth_scene* s, int top_depth, int mesh_depth, int tree_mode) {
+    if (!s || top_depth < 0 || mesh_depth < 0 || tree_mode < 0 || tree_mode > 1) return RT_ERR_ARG;
     if (top_depth > RT_MAX_TOP_DEPTH || mesh_depth > RT_MAX_TREE_DEPTH) return RT_ERR_LIMIT;
     return guarded([&] {
         s->settings.tree_subdivide = (unsigned)mesh_depth;
+        s->settings.tree_mode = tree_mode;
         s->scene.applySettings(s->settings);
         s->scene.topDepthLimit = top_depth;
         s->scene.buildSceneBvh();

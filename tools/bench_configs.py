@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--ppm", default="", help="also write the frame as a P3 file (main.cpp:245-255)")
+    ap.add_argument("--tree-mode", type=int, default=0, help="1: binned-SAH mesh trees (free topology, no parity; SURVEY 8(f).2)")
+    ap.add_argument("--mesh-depth", type=int, default=0)
     args = ap.parse_args()
     import torch
     if not torch.cuda.is_available():
@@ -44,7 +46,7 @@ def main():
     name, td, md, W, H, spp, depth = CONFIGS[args.config]
     spp = args.spp or spp
     depth = args.depth or depth
-    scene = rt.HostScene(name, td, md)
+    scene = rt.HostScene(name, td, args.mesh_depth or md, args.tree_mode)
     ctx = rt.Context(0)
     ctx.upload_scene(scene)
     ctx.set_camera(rt.default_camera(W / H))
@@ -76,7 +78,7 @@ def main():
     el = time.perf_counter() - t0
     k = args.steps
     print(json.dumps({
-        "config": args.config, "scene": name, "width": W, "height": H, "spp": spp, "max_depth": depth,
+        "config": args.config, "scene": name, "tree_mode": args.tree_mode, "width": W, "height": H, "spp": spp, "max_depth": depth,
         "ms_per_frame": round(el / k * 1e3, 2), "mrays_per_s": round(tot["rays"] / el / 1e6, 2),
         "rays_per_frame": {c: tot[c] // k for c in ("primary", "secondary", "shadow")},
         "kernel_ms_per_frame": {"k_shadow": round(tot["ms_shadow"] / k, 2), "k_closest": round(tot["ms_closest"] / k, 2)},
