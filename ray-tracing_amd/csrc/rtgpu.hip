@@ -69,7 +69,9 @@ struct rt_ctx {
     unsigned long long queued_samples = 0;
 
     DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays, dtex, ovf;
-    uint32_t batch = 1u << 20;
+    uint32_t batch = 8u << 20;    /* path states per wavefront iteration (RT_BATCH). One batch of diffuse hits is one launch of the persistent shadow kernel, and
+                                   * every launch ends in a tail of a few ms in which the longest rays finish alone: measured on C5 at 1 / 4 / 8 Mi states
+                                   * 1112 / 1244 / 1280 Mrays/s (gorilla 75.6 / 65.8 / 61.8 ms per frame with 1 / 4 / 16 Mi) */
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
     int front_state = -1;       /* the front pass of the shadow rays (k_shadow_front): -1 = to be probed on this scene, 0 = off, 1 = on */
@@ -238,7 +240,8 @@ int wide_ovf_cap(const rt_ctx* c, int* lds_cap_out) {
 
 /* the library's own buffers, grown to what this run can need */
 int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
-    const uint32_t B = c->batch;
+    /* no more states per iteration than the call has primaries (a small frame must not size the buffers of a big one) */
+    const uint32_t B = (uint32_t)std::min<unsigned long long>(c->batch, (std::max<unsigned long long>(src.total, 4096ull) + 1023ull) & ~1023ull);
     const int L = c->n_lights;
     const int S = c->fr.shadow_mode == 1 ? 1 : c->fr.light_samples;
     size_t need_stack = (size_t)B * (size_t)(src.max_depth + 3);
@@ -251,9 +254,10 @@ int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
     if ((rc = ensure(c, c->cnt, (size_t)B * std::max(L, 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->ctr, sizeof(Counters)))) return rc;
     if (src.from_tiles && (rc = ensure(c, c->tilebuf, std::max<size_t>(c->tiles.size(), 1) * sizeof(TileD)))) return rc;
-    /* the records of a batch are processed in chunks so that the 32-byte ray buffer stays below ~2 GiB */
     const unsigned long long per_rec = (unsigned long long)std::max(L, 1) * S;
-    const unsigned long long chunk = std::max<unsigned long long>(1ull, std::min<unsigned long long>(B, (64ull << 20) / per_rec));
+    unsigned long long ray_cap = 320ull << 20;                  /* rays per k_shadow launch (10 GiB of 32-byte rays; HBM is 288 GB): a batch of 8 Mi hits x 35 samples is one launch */
+    if (const char* e = getenv("RT_SHADOW_RAYS")) ray_cap = std::max<unsigned long long>(1ull << 16, strtoull(e, nullptr, 10));
+    const unsigned long long chunk = std::max<unsigned long long>(1ull, std::min<unsigned long long>(B, ray_cap / per_rec));
     const bool direct = c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW");
     if (!direct && L > 0 && (rc = ensure(c, c->srays, (size_t)(chunk * per_rec) * 2 * sizeof(float4)))) return rc;
     const int ovf_cap = wide_ovf_cap(c, nullptr);
