@@ -19,7 +19,7 @@ Prints ONE JSON line on rank 0 (the repo's bench contract):
                walk stops at the first occluder, prunes and reads quantised nodes; results are bit-identical).
   cpu_baseline the oracle (CPU restatement of the reference path, ThreadPool-equivalent) timed on this host on
                a centred 256x256 crop with 0.6 x cores (main.cpp:61) and with all cores of this process.
-  config       also carries BASELINE's second half: ms/frame of the mesh scenes (C4 gorilla and cow) and C3.
+  config       also carries BASELINE's second half: ms/frame of the mesh scenes (C4 gorilla and cow), and C1-C3.
 """
 import argparse
 import importlib
@@ -41,7 +41,9 @@ PER_RAY_FILE = os.path.join(ROOT, "profiles", "c5_per_ray.json")
 PMC_FILE = os.path.join(ROOT, "profiles", "c5_k_shadow_pmc.json")
 CHECKSUM_FILE = os.path.join(ROOT, "profiles", "c5_checksum.json")   # frame checksums of the plain reference-order traversal
 
-SIDE_CONFIGS = {   # BASELINE configs 3 and 4: name -> (scene, width, height, spp, max_depth)
+SIDE_CONFIGS = {   # BASELINE configs 1-4: name -> (scene, width, height, spp, max_depth)
+    "C1_default_scene_480_30spp": ("final", 480, 480, 30, 50),
+    "C2_default_scene_480_16spp": ("final", 480, 480, 16, 50),
     "C3_refraction_1080p": ("refraction", 1920, 1080, 30, 5),
     "C4_mesh_gorilla_1080p": ("mesh_gorilla", 1920, 1080, 30, 50),
     "C4_mesh_cow_1080p": ("mesh_cow", 1920, 1080, 30, 50),
@@ -89,8 +91,10 @@ def time_side_config(rt, torch, device, name):
             rays += step().rays
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        st = ctx.stats()
         return {"ms_per_frame": round(el / k * 1e3, 2), "mrays_per_s": round(rays / el / 1e6, 1), "spp": spp, "max_depth": depth,
-                "frame_checksum": float(frame.double().sum().item())}
+                "rays_traced_per_frame": st.rays, "shadow_rays_culled_per_frame": st.rays_shadow_culled,
+                "frame_checksum": float(np.nan_to_num(frame.double().cpu().numpy(), nan=0.0, posinf=0.0, neginf=0.0).sum())}
     finally:
         ctx.close()
 

@@ -135,7 +135,10 @@ typedef struct {
     uint64_t rays_primary, rays_secondary, rays_shadow;   /* one ray = one BVH_Node::intersectObjects query */
     uint64_t nonfinite;         /* radiance contributions that were NaN/Inf (dropped from the sum) */
     uint64_t iterations;        /* wavefront iterations */
-    uint64_t pad0;
+    uint64_t rays_shadow_culled; /* shadow rays NOT traced: their hit's whole Phong term, weighted by the path's throughput, lies below half a
+                                  * unit of the frame's fixed-point accumulators whatever the shadow factor, so the frame's bits do not depend
+                                  * on them (depth-50 glass recursions end in billions of such hits). Scene::isInShadow calls of the CPU path
+                                  * = rays_shadow + rays_shadow_culled. RT_NO_CULL=1 traces them all. */
     double ms_total;            /* device time of the frame (HIP events) */
     double ms_closest;          /* sum over launches of the closest-hit+shade kernel */
     double ms_shadow;           /* sum over launches of the shadow kernel */

@@ -96,13 +96,19 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
-                ("nonfinite", C.c_uint64), ("iterations", C.c_uint64), ("pad0", C.c_uint64),
+                ("nonfinite", C.c_uint64), ("iterations", C.c_uint64), ("rays_shadow_culled", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_closest", C.c_double), ("ms_shadow", C.c_double),
                 ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64), ("peak_states", C.c_uint64)]
 
     @property
     def rays(self):
+        """Rays traced (one ray = one BVH_Node::intersectObjects query)."""
         return self.rays_primary + self.rays_secondary + self.rays_shadow
+
+    @property
+    def shadow_queries(self):
+        """Scene::isInShadow calls of the CPU path for the same frame: traced + culled (see rtgpu.h, rays_shadow_culled)."""
+        return self.rays_shadow + self.rays_shadow_culled
 
 
 HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "<f4"),

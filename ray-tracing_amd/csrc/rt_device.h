@@ -110,6 +110,9 @@ struct DScene {
     int32_t top_blob_bytes;
     int32_t top_off[7];         /* ... and tsub: per top-level leaf the root of the sub-tree over its objects, or LINK_NONE */
     int32_t has_topsub;         /* some top-level leaves carry a sub-tree over their objects (rtgpu.hip) */
+    float light_sum;            /* sum over the lights of their largest colour component; < 0: contribution culling off (k_closest) */
+    const float* cull_gpow;     /* [RT_MAX_PATH_DEPTH + 2]: entry r bounds how much a path's throughput can grow over r more bounces (k_closest) */
+    float cull_cmax;            /* what one hit (or the sky) can add per unit of throughput, any material of the scene; < 0: no culling of path states */
 };
 /* head of section 6 of top_blob, in front of tsub */
 struct TopFrame {

@@ -42,6 +42,7 @@ struct Counters {
     unsigned long long work;        /* next unclaimed shadow-ray index of the running k_shadow launch */
     unsigned long long deferred;    /* rays k_shadow_front handed to the running k_shadow launch */
     unsigned long long deferred_sum; /* ... to all launches of this frame */
+    unsigned long long culled;       /* diffuse hits k_closest dropped because they cannot change the frame (contribution culling) */
     unsigned long long sh_node_steps, sh_tri_steps, sh_other_steps, sh_loop_iters;   /* RT_COUNT=1 diagnostics */
     unsigned long long sh_node_iters, sh_tri_iters, sh_top_iters, sh_top_lanes;
     unsigned long long sh_m1_node, sh_m1_tri, sh_m1_rays;   /* steps taken and rays finished in mode 1 (the second walk of shadow_walk) */
@@ -581,7 +582,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
     const int stride = blockDim.x;
 
     uint32_t want_child = 0;
-    bool want_diffuse = false;
+    bool want_diffuse = false, culled = false;
     F3 c_o[2], c_d[2], c_thr[2];
     uint64_t c_code[2];
     DiffuseRec rec;
@@ -643,6 +644,27 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
             }
             if (m.type == 0 || m.type == 3 || remaining <= 0) {   /* Scene.h:204-222: shaded after the shadow pass */
                 want_diffuse = true;
+                /* Contribution culling. The hit adds thr * f * colour to its pixel, f in [0, 1] the shadow factor and colour the
+                 * Phong sum over the lights (k_shade), and the sum goes through accumulate() channel by channel: a value below
+                 * half a unit of the fixed-point accumulator (2^-37) adds exactly nothing. |colour| is bounded without tracing a
+                 * single shadow ray: per light, Li * (ka + kd * |theta| + ks * pow(max(0, r.V), shininess)) with |theta| <= |N|
+                 * (|Ldir| = 1) and |r.V| <= 2 |theta| |N| + 1. If max|thr| times that bound stays below 2^-39 (a factor four for
+                 * the float rounding of the products) the hit cannot change a bit of the frame and its light_samples x lights
+                 * shadow rays are not traced -- they are counted (rt_stats::rays_shadow_culled). A depth-50 recursion inside a
+                 * glass mesh ends in billions of such hits: every internal reflection takes (1 - transparency) * R off the
+                 * throughput. NaN and infinite throughputs compare false and are kept. */
+                const float tmax = fmaxf(fabsf(thr.x), fmaxf(fabsf(thr.y), fabsf(thr.z)));
+                if (sc.light_sum >= 0.f && tmax < 1e-7f) {
+                    const float nl = len(h.n) * 1.0001f;
+                    float kmax = fmaxf(fmaxf(fabsf(m.kd[0]), fabsf(m.kd[1])), fmaxf(fabsf(m.kd[2]), fmaxf(fabsf(m.ks[0]), fmaxf(fabsf(m.ks[1]), fabsf(m.ks[2])))));
+                    if (matword & 0xC0000000u) kmax = fmaxf(kmax, 1.0f);              /* checker colour / texel: at most 1 */
+                    const float amax = fmaxf(fabsf(m.ka[0]), fmaxf(fabsf(m.ka[1]), fabsf(m.ka[2])));
+                    const double rv = 2.0 * (double)nl * (double)nl + 1.0;
+                    const double spec = m.shininess > 0.0 ? pow(rv, m.shininess) : (m.shininess == 0.0 ? 1.0 : (double)INFINITY);   /* (a negative exponent has no bound: pow(0+, -s)) */
+                    const double cmax = (double)sc.light_sum * ((double)amax + (double)kmax * ((double)nl + spec)) * 1.01;
+                    if ((double)tmax * cmax < 1.8189894035458565e-12) want_diffuse = false;        /* 2^-39 */
+                }
+                if (!want_diffuse) culled = true;
                 F3 V = mul(-1.f, r.d);
                 rec.P[0] = h.pos.x; rec.P[1] = h.pos.y; rec.P[2] = h.pos.z;
                 rec.N[0] = h.n.x; rec.N[1] = h.n.y; rec.N[2] = h.n.z;
@@ -695,6 +717,30 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
         }
     }
 
+    {   /* culled hits: one atomic per wave that has any */
+        const unsigned long long cm = __ballot(culled);
+        if (cm && __lane_id() == 0) atomicAdd(&ctr->culled, (unsigned long long)__popcll(cm));
+    }
+    /* The same argument one level up: a child state whose throughput is so small that nothing below it can reach half a unit
+     * of the accumulators is not traced. Per bounce a throughput grows by at most G (mirror: reflectivity * ks; glass: the
+     * larger of (1 - transparency) * Rmax and (1 - transparency) * max(1, Rmax - 1) + transparency, Rmax the Schlick term at
+     * cos = -|N| -- the reference evaluates (1 - cos)^5 for rays inside the medium too, Material.h:79-84 -- and the absorption
+     * factor is at most 1), so over the r bounces it has left, by at most cull_gpow[r], and what a hit or the sky adds per unit
+     * of throughput is at most cull_cmax (host: rt_upload_scene; off for scenes with non-finite normals or unbounded
+     * materials). The depth-50 recursion inside a glass mesh loses a factor (1 - transparency) * R per internal reflection:
+     * its tree is cut where it stops mattering instead of growing 1.43x per level down to depth 50. */
+    if (want_child && sc.cull_cmax >= 0.f) {
+        const float g = sc.cull_gpow[remaining > 0 ? remaining - 1 : 0] * sc.cull_cmax;
+        uint32_t keep = 0;
+        for (uint32_t k = 0; k < want_child; k++) {
+            const float tm = fmaxf(fabsf(c_thr[k].x), fmaxf(fabsf(c_thr[k].y), fabsf(c_thr[k].z)));
+            if (!((double)tm * (double)g < 1.8189894035458565e-12)) {      /* 2^-39; NaN / inf stay */
+                if (keep != k) { c_o[keep] = c_o[k]; c_d[keep] = c_d[k]; c_thr[keep] = c_thr[k]; c_code[keep] = c_code[k]; }
+                keep++;
+            }
+        }
+        want_child = keep;
+    }
     /* queue appends (the ray statistics are the host's: it knows how many states of a batch are fresh primaries) */
     uint32_t cbase, dbase;
     block_reserve2(ctr, want_child, want_diffuse ? 1u : 0u, reinterpret_cast<uint32_t*>(s_stack + (size_t)sc.cstack_cap * blockDim.x), cbase, dbase);
@@ -730,7 +776,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
 #define ST_MESH 2             /* inside a mesh tree with a step to take */
 #define ST_BLOCKED 3          /* inside a mesh tree, waiting for its pending leaf to be tested (see can_walk) */
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 8       /* refill once this many lanes are idle */
+#define RT_REFILL_MIN 16      /* refill once this many lanes are idle (4 / 8 / 16 / 24 / 32: 229.7 / 219.7 / 215.3 / 223.8 / 240.3 ms on the reduced C5 frame; gorilla, cow, chamber -2..3 % at 16) */
 #endif
 #ifndef RT_GRAB
 #define RT_GRAB 512u           /* rays a wave takes from the global counter at a time */

@@ -460,6 +460,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->stats.nonfinite += c->h_ctr->nonfinite;
+    c->stats.rays_shadow_culled += c->h_ctr->culled * (unsigned long long)L * (unsigned long long)S;
     if (c->count_steps)
         fprintf(stderr, "[rtgpu] shadow steps: node %llu tri %llu other %llu lane-iterations %llu rays %llu; wave iterations: node %llu tri %llu top %llu (top lanes %llu)\n",
                 c->h_ctr->sh_node_steps, c->h_ctr->sh_tri_steps, c->h_ctr->sh_other_steps, c->h_ctr->sh_loop_iters, c->h_ctr->rays_shadow,
@@ -1622,6 +1623,57 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     sc.wstack_cap = sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 3 + (has_topsub ? 3 * max_wide_top_depth + 2 : 0);
     sc.has_sub = subs.empty() ? 0 : 1;
     sc.has_topsub = has_topsub ? 1 : 0;
+    {   /* contribution culling (k_closest): the bound needs finite, non-negative light colours */
+        double sum = 0.0;
+        bool ok = !getenv("RT_NO_CULL");
+        for (int i = 0; i < d->n_lights; i++) {
+            double mx = 0.0;
+            for (int k = 0; k < 3; k++) { const double v = std::fabs((double)d->lights[i].color[k]); if (!(v < 1e30)) ok = false; mx = std::max(mx, v); }
+            sum += mx;
+        }
+        sc.light_sum = ok ? (float)(sum * 1.0001) : -1.f;
+        /* culling of path states: G (growth of a throughput per bounce) and C (what a hit adds per unit of throughput) over all
+         * materials; needs finite geometry (a NaN normal below a culled state would have reached the frame as a NaN) */
+        bool states = ok;
+        for (int64_t i = 0; i < 3 * d->n_verts && states; i++) if (!(std::fabs(d->normals[i]) < 1e30f) || !(std::fabs(d->positions[i]) < 1e30f)) states = false;
+        double G = 1.0, Cm = 1.0;                        /* the sky adds at most 1 per unit (Scene.h:274-278) */
+        for (int i = 0; i < d->n_materials && states; i++) {
+            const rt_material& m = d->materials[i];
+            const double nmax = m.normal_map ? 3.0003 : 1.0002;     /* |N| after Material::applyTBN: at most |t| + |b| + |n| with texels in [0, 1] */
+            double kmax = 0.0, amax = 0.0, kdmax = -INFINITY;
+            for (int k = 0; k < 3; k++) {
+                kmax = std::max(kmax, std::max(std::fabs((double)m.kd[k]), std::fabs((double)m.ks[k])));
+                amax = std::max(amax, std::fabs((double)m.ka[k]));
+                kdmax = std::max(kdmax, (double)m.kd[k]);
+            }
+            if (m.texture || m.type == RT_MAT_CHECKER) kmax = std::max(kmax, 1.0);
+            if (!(kmax < 1e30) || !(amax < 1e30) || !(m.shininess >= 0.0) || !(m.shininess < 1e6)) { states = false; break; }
+            const double spec = std::pow(2.0 * nmax * nmax + 1.0, m.shininess);
+            Cm = std::max(Cm, sum * 1.0001 * (amax + kmax * (nmax + spec)) * 1.01);
+            if (m.type == RT_MAT_MIRROR) {
+                double ks = 0.0;
+                for (int k = 0; k < 3; k++) ks = std::max(ks, std::fabs((double)m.ks[k]));
+                if (m.texture) ks = std::max(ks, 1.0);          /* ks = the texel (Scene.h:189-191) */
+                G = std::max(G, std::fabs((double)m.reflectivity) * ks * 1.001);
+            } else if (m.type == RT_MAT_GLASS) {
+                if (!(kdmax <= 1.0) || !(m.transparency >= 0.f) || !(m.ior > 0.f)) { states = false; break; }     /* absorption exp(-(1 - kd) t transparency) <= 1 needs these */
+                const double ri = m.ior, r0 = ((1.0 - ri) / (1.0 + ri)) * ((1.0 - ri) / (1.0 + ri));
+                const double rmax = r0 + (1.0 - r0) * std::pow(1.0 + nmax, 5.0);
+                const double omtr = std::fabs(1.0 - (double)m.transparency);
+                G = std::max(G, std::max(omtr * rmax, omtr * std::max(1.0, rmax - 1.0) + (double)m.transparency) * 1.001);
+            }
+        }
+        if (!(Cm < 1e30) || !(G < 1e30)) states = false;
+        std::vector<float> gpow((size_t)RT_MAX_PATH_DEPTH + 2, INFINITY);
+        if (states) {
+            double acc = 1.0;
+            for (size_t r = 0; r < gpow.size(); r++) { gpow[r] = acc < 1e37 ? (float)(acc * 1.0001) : INFINITY; acc *= G; }
+        }
+        if ((rc = upload(c, gpow, &sc.cull_gpow))) { free_scene(c); return rc; }
+        sc.cull_cmax = states ? (float)(Cm * 1.0001) : -1.f;
+        if (c->debug) fprintf(stderr, "[rtgpu] contribution culling: hits %s, path states %s (growth per bounce <= %g, a hit adds <= %g per unit of throughput)\n",
+                              ok ? "on" : "off", states ? "on" : "off", G, Cm);
+    }
 
     sc.quant_ok = (quant_ok && !getenv("RT_SHADOW_EXACT_NODES")) ? 1 : 0;
     {   /* The per-lane stacks of the walks live in LDS (4 bytes x entries x threads of the block; k_shadow's wide stack spills
@@ -1786,7 +1838,7 @@ int rt_flush(rt_ctx* c) {
         rt_stats t{};
         for (rt_ctx* q : c->subs) {
             const rt_stats& s = q->stats;
-            t.rays_primary += s.rays_primary; t.rays_secondary += s.rays_secondary; t.rays_shadow += s.rays_shadow; t.nonfinite += s.nonfinite;
+            t.rays_primary += s.rays_primary; t.rays_secondary += s.rays_secondary; t.rays_shadow += s.rays_shadow; t.rays_shadow_culled += s.rays_shadow_culled; t.nonfinite += s.nonfinite;
             t.iterations = std::max(t.iterations, s.iterations); t.peak_states = std::max(t.peak_states, s.peak_states);
             t.ms_total = std::max(t.ms_total, s.ms_total); t.ms_closest += s.ms_closest; t.ms_shadow += s.ms_shadow;
             t.launches_closest += s.launches_closest; t.launches_shadow += s.launches_shadow;

@@ -232,7 +232,8 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
     # ... and top-level rounds of k_shadow that never wait / wait for 48 lanes, top-level tables read from global memory
     for knob, value in (("RT_NO_LEAF_SPLIT", "1"), ("RT_FORCE_LEAF_SPLIT", "1"), ("RT_TOP_MIN", "1"), ("RT_TOP_MIN", "48"),
                         ("RT_TOP_GLOBAL", "1"), ("RT_FRONT", "1"), ("RT_FRONT", "0"),       # ... with and without the front pass
-                        ("RT_NO_TOP_SPLIT", "1")):                                       # ... top-level leaves scanned object by object (no sub-trees over their objects)
+                        ("RT_NO_TOP_SPLIT", "1"),                                        # ... top-level leaves scanned object by object (no sub-trees over their objects)
+                        ("RT_NO_CULL", "1")):                                            # ... every hit shaded and every path followed, however little it carries
         monkeypatch.setenv(knob, value)
         c5 = rt.Context(0)
         try:
@@ -241,7 +242,11 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
         finally:
             c5.close()
         monkeypatch.delenv(knob)
-        assert np.array_equal(bits(other), bits(quant)) and np.array_equal(oprim, qprim) and ost.rays_shadow == qst.rays_shadow, (knob, value)
+        assert np.array_equal(bits(other), bits(quant)) and np.array_equal(oprim, qprim), (knob, value)
+        if knob == "RT_NO_CULL":        # (path states that carry nothing -- a glass of transparency 1 reflects with weight 0 -- are followed now, and their hits counted)
+            assert ost.rays_shadow >= qst.shadow_queries and ost.rays_secondary >= qst.rays_secondary and ost.rays_shadow_culled == 0
+        else:
+            assert ost.rays_shadow == qst.rays_shadow and ost.rays_secondary == qst.rays_secondary, (knob, value)
     # shrink one child box of a mesh root below its own children's boxes: not nested any more
     dp = hs.desc
     d = dp.contents
@@ -550,3 +555,26 @@ def test_call_order_and_limits(rt):
         upload()                                         # restored: accepted again
     finally:
         c.close()
+
+
+def test_contribution_culling_does_not_change_a_bit(rt, ctx, monkeypatch):
+    """Hits and path states that cannot reach half a unit of the fixed-point accumulators are not traced (k_closest): the
+    depth-50 recursion inside the default scene's glass meshes is cut where it stops mattering. The frame must be the
+    one that follows every path to the end, bit for bit, on the view where the recursion explodes."""
+    hs, _ = scene_pair(rt, ctx, "final")
+    cam = rt.default_camera(1.0, zoom=25.0)
+    p = rt.make_params(40, 40, spp=1, max_depth=50, light_samples=35, shadow_mode=0, jitter=1, seed=8)
+    culled, cprim, cst = ctx.render(cam, p)
+    monkeypatch.setenv("RT_NO_CULL", "1")
+    full_ctx = rt.Context(0)
+    try:
+        full_ctx.upload_scene(hs)
+        full, fprim, fst = full_ctx.render(cam, p)
+    finally:
+        full_ctx.close()
+    monkeypatch.delenv("RT_NO_CULL")
+    assert np.array_equal(bits(culled), bits(full)) and np.array_equal(cprim, fprim)
+    assert fst.rays_shadow_culled == 0 and cst.rays_shadow_culled > 0
+    assert cst.rays_secondary < fst.rays_secondary and cst.rays_primary == fst.rays_primary
+    assert cst.shadow_queries <= fst.rays_shadow          # (hits below culled path states are not even counted)
+    print(f"rays traced with / without culling: {cst.rays} / {fst.rays}")

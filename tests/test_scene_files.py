@@ -126,7 +126,7 @@ def test_malformed_inputs_are_refused_not_crashed(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,depth", [("final", 6), ("reflexion_chamber", 50)])
-def test_saved_scene_renders_like_the_original_on_the_gpu(ctx, tmp_path, name, depth):
+def test_saved_scene_renders_like_the_original_on_the_gpu(ctx, tmp_path, monkeypatch, name, depth):
     """SURVEY 8(f).3 on the device: Scene::save -> Scene::load -> upload -> render gives the bits of the scene that was
     never saved, and both meet the oracle's frame within 1/255 on the 8-bit output (hit ids and ray counts exact)."""
     import oracle_lib as O
@@ -150,5 +150,13 @@ def test_saved_scene_renders_like_the_original_on_the_gpu(ctx, tmp_path, name, d
     want = oprim.astype(np.int64)
     want[oprim[..., 0] < 0] = 0xFFFFFFFF
     assert np.array_equal(prim_b.astype(np.int64), want)
-    assert (st_b.rays_primary, st_b.rays_secondary, st_b.rays_shadow) == (ost.rays_primary, ost.rays_secondary, ost.rays_shadow)
+    # ray counts against the CPU path: with every hit shaded and every path followed (by default the library drops what cannot
+    # change the frame, rtgpu.h rays_shadow_culled) -- and that frame has the same bits
+    monkeypatch.setenv("RT_NO_CULL", "1")
+    ctx.upload_scene(back)
+    monkeypatch.delenv("RT_NO_CULL")
+    rgb_c, prim_c, st_c = ctx.render(cam, p)
+    assert np.array_equal(rgb_c.view(np.uint32), rgb_b.view(np.uint32))
+    assert (st_c.rays_primary, st_c.rays_secondary, st_c.rays_shadow) == (ost.rays_primary, ost.rays_secondary, ost.rays_shadow)
+    assert st_b.rays_secondary <= st_c.rays_secondary and st_b.shadow_queries <= st_c.rays_shadow
     assert np.abs(O.quantize(np.nan_to_num(rgb_b)) - O.quantize(np.nan_to_num(orgb))).max() <= 1      # tolerance: 1/255 (north_star)
