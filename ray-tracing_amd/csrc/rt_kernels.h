@@ -90,32 +90,41 @@ RT_DEV float max_abs_inv(const Ray& r) {
 RT_DEV bool beyond(float tEnter, float slack, float bound) { return (tEnter - slack) * 0.99999f > bound; }
 
 /* ---- a ray in the 16-bit plane frame of a mesh (see "quantised shadow nodes" further down): plane time =
- * q*qa + qn (entry planes) / qf (exit planes) */
+ * q*qa + qn (entry planes) / qf (exit planes).
+ * A packed pair of planes (lo | hi << 16) is never converted to float: one v_perm_b32 drops the 16-bit plane into the
+ * mantissa of 2^23 (bytes: 0x4B, 0x00, plane), which IS the float 8388608 + q, and which half it takes -- the plane the
+ * ray enters through or the one it leaves through, AccelerationStruct.cpp:22 -- is the selector, a per-ray constant. That
+ * replaces a rotate and two conversions per axis and child by two permutes. qn and qf absorb the 2^23: the constant
+ * c - 2^23*qa is rounded to half a unit of |qa| at worst, i.e. half a quantum of the frame in time, so both are widened by a
+ * whole one (on top of the slack for the rounding of the plane arithmetic itself). */
 struct QuantRay {
     F3 qa, qn, qf;
-    uint32_t rot[3];    /* 16 where 1/d < 0: swaps the lo and hi halves of a packed plane pair */
+    uint32_t seln[3];             /* v_perm_b32 selectors: the half of a plane pair the ray enters through (the other half: ^ QUANT_SEL_FLIP) */
 };
+#define QUANT_SEL_LO 0x070C0100u
+#define QUANT_SEL_HI 0x070C0302u
+#define QUANT_SEL_FLIP 0x00000202u
+RT_DEV float quant_plane(uint32_t w, uint32_t sel) { return __uint_as_float(__builtin_amdgcn_perm(0x4B000000u, w, sel)); }
 RT_DEV void quant_setup(QuantRay& q, const Ray& r, const DMesh& m) {
     float M = 1.01f * fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fmaxf(fabsf(r.o.z), m.amax));
     float ix = fabsf(r.inv.x), iy = fabsf(r.inv.y), iz = fabsf(r.inv.z);
     /* an infinite 1/d gives NaN or +-inf plane times in both forms; its slack is irrelevant, 0 keeps the constants clean */
-    float ex = 2e-6f * M * (ix < INFINITY ? ix : 0.f), ey = 2e-6f * M * (iy < INFINITY ? iy : 0.f), ez = 2e-6f * M * (iz < INFINITY ? iz : 0.f);
     q.qa = f3(m.qstep[0] * r.inv.x, m.qstep[1] * r.inv.y, m.qstep[2] * r.inv.z);
+    float ex = 2e-6f * M * (ix < INFINITY ? ix : 0.f) + fabsf(q.qa.x), ey = 2e-6f * M * (iy < INFINITY ? iy : 0.f) + fabsf(q.qa.y),
+          ez = 2e-6f * M * (iz < INFINITY ? iz : 0.f) + fabsf(q.qa.z);
     float bx = (m.qmin[0] - r.o.x) * r.inv.x, by = (m.qmin[1] - r.o.y) * r.inv.y, bz = (m.qmin[2] - r.o.z) * r.inv.z;
-    q.qn = f3(bx - ex, by - ey, bz - ez);
-    q.qf = f3(bx + ex, by + ey, bz + ez);
-    q.rot[0] = r.inv.x < 0.0f ? 16u : 0u;      /* a negative 1/d swaps the roles of the two planes (AccelerationStruct.cpp:22) */
-    q.rot[1] = r.inv.y < 0.0f ? 16u : 0u;
-    q.rot[2] = r.inv.z < 0.0f ? 16u : 0u;
+    q.qn = f3(__builtin_fmaf(-8388608.0f, q.qa.x, bx - ex), __builtin_fmaf(-8388608.0f, q.qa.y, by - ey), __builtin_fmaf(-8388608.0f, q.qa.z, bz - ez));
+    q.qf = f3(__builtin_fmaf(-8388608.0f, q.qa.x, bx + ex), __builtin_fmaf(-8388608.0f, q.qa.y, by + ey), __builtin_fmaf(-8388608.0f, q.qa.z, bz + ez));
+    const bool sx = r.inv.x < 0.0f, sy = r.inv.y < 0.0f, sz = r.inv.z < 0.0f;      /* a negative 1/d swaps the roles of the two planes (AccelerationStruct.cpp:22) */
+    q.seln[0] = sx ? QUANT_SEL_HI : QUANT_SEL_LO;
+    q.seln[1] = sy ? QUANT_SEL_HI : QUANT_SEL_LO;
+    q.seln[2] = sz ? QUANT_SEL_HI : QUANT_SEL_LO;
 }
-/* conservative entry time of one quantised box (three packed plane pairs); hit = the slab is not empty within [0, lim] */
+/* conservative entry time of one quantised box (three packed plane pairs); hit = the slab is not empty within [lo, lim] */
 RT_DEV float quant_entry(uint32_t wx, uint32_t wy, uint32_t wz, const QuantRay& s, float lim, bool& hit, float lo = 0.0f) {
-    wx = __builtin_amdgcn_alignbit(wx, wx, s.rot[0]);
-    wy = __builtin_amdgcn_alignbit(wy, wy, s.rot[1]);
-    wz = __builtin_amdgcn_alignbit(wz, wz, s.rot[2]);
-    float a = __builtin_fmaf((float)(wx & 0xFFFFu), s.qa.x, s.qn.x), d = __builtin_fmaf((float)(wx >> 16), s.qa.x, s.qf.x);
-    float b = __builtin_fmaf((float)(wy & 0xFFFFu), s.qa.y, s.qn.y), e = __builtin_fmaf((float)(wy >> 16), s.qa.y, s.qf.y);
-    float c = __builtin_fmaf((float)(wz & 0xFFFFu), s.qa.z, s.qn.z), f = __builtin_fmaf((float)(wz >> 16), s.qa.z, s.qf.z);
+    float a = __builtin_fmaf(quant_plane(wx, s.seln[0]), s.qa.x, s.qn.x), d = __builtin_fmaf(quant_plane(wx, s.seln[0] ^ QUANT_SEL_FLIP), s.qa.x, s.qf.x);
+    float b = __builtin_fmaf(quant_plane(wy, s.seln[1]), s.qa.y, s.qn.y), e = __builtin_fmaf(quant_plane(wy, s.seln[1] ^ QUANT_SEL_FLIP), s.qa.y, s.qf.y);
+    float c = __builtin_fmaf(quant_plane(wz, s.seln[2]), s.qa.z, s.qn.z), f = __builtin_fmaf(quant_plane(wz, s.seln[2] ^ QUANT_SEL_FLIP), s.qa.z, s.qf.z);
     float tMin = fmaxf(fmaxf(fmaxf(a, b), c), lo);
     float tMax = fminf(fminf(fminf(d, e), f), lim);
     hit = tMin <= tMax;
