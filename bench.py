@@ -264,7 +264,7 @@ def main():
                            f"(35 samples/light), depth {args.depth}, mesh BVH depth {args.mesh_depth}, counter RNG",
                "tiles": "32x32, round-robin per tile row with a hashed row offset", "parallelism": f"tile-sharded x{world}",
                "gather": f"all-gather of packed tile slabs, {gather.bytes_sent_per_rank()} B per rank" if world > 1 else "none (one rank)",
-               "rays_primary": prim, "rays_secondary": sec, "rays_shadow": shad,
+               "rays_per_frame": {"primary": prim // args.steps, "secondary": sec // args.steps, "shadow": shad // args.steps},
                "kernel_ms_per_step": {"k_shadow": round(ms_shadow / args.steps, 2), "k_closest": round(ms_closest / args.steps, 2)},
                "scene_build_s": round(t_build, 2), "upload_s": round(t_upload, 2), "frame_checksum": checksum,
                "frame_checksum_matches_reference_order_traversal": checksum_ok}
