@@ -56,6 +56,8 @@ struct Material {
 struct Image { int width = 0, height = 0, channels = 0; std::vector<uint8_t> data; };   /* stbi_load result */
 /* Binary PPM (P6, maxval 255), the format of the reference's .ppm textures and normal maps. */
 bool load_ppm(const std::string& filename, Image& out);
+bool load_png(const std::string& filename, Image& out);     /* 8-bit, non-interlaced grey / grey+alpha / RGB / RGBA */
+bool load_image(const std::string& filename, Image& out);   /* by extension: .ppm, .png; x.jpg reads the decoded x.ppm beside it */
 
 struct AABB {                 /* AccelerationStruct.h:11-70 */
     Vec3 min, max;
@@ -155,6 +157,7 @@ public:
     bool setup_refraction_scene();                      /* Scene.h:468-552 */
     bool setup_reflexion_scene();                       /* Scene.h:554-599 */
     bool setup_reflexion_chamber();                     /* Scene.h:601-714 */
+    bool setup_cornell_box();                           /* Scene.h:288-466 */
     bool setup_final_scene();                           /* Scene.h:800-970 */
     /* Material::loadTexture / loadNormalMap (Material.h:128-138) for files under the image directory; -1 on failure */
     int loadImage(const std::string& relative_path);

@@ -24,6 +24,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <zlib.h>      /* inflate, for the PNG reader only */
 
 namespace {
 
@@ -775,10 +776,83 @@ bool load_ppm(const std::string& path, int& w, int& h, std::vector<uint8_t>& px)
     fclose(f);
     return ok;
 }
+/* PNG as stbi_load(..., 0) returns it for the reference's .png assets: 8 bits per sample, not interlaced, grey /
+ * grey+alpha / RGB / RGBA, no palette, no tRNS (anything else is refused, not guessed): the IDAT stream inflated,
+ * each row's filter (none, sub, up, average, Paeth -- PNG specification, section 9) undone; channels as in the file. */
+bool load_png(const std::string& path, int& w, int& h, int& ch, std::vector<uint8_t>& px) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> file;
+    uint8_t buf[65536];
+    for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;) file.insert(file.end(), buf, buf + n);
+    fclose(f);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) return false;
+    auto be32 = [&](size_t o) { return ((uint32_t)file[o] << 24) | ((uint32_t)file[o + 1] << 16) | ((uint32_t)file[o + 2] << 8) | file[o + 3]; };
+    std::vector<uint8_t> z;
+    bool header = false;
+    w = h = ch = 0;
+    for (size_t o = 8; o + 12 <= file.size();) {
+        uint32_t len = be32(o);
+        if (len > file.size() - o - 12) return false;
+        const char* type = (const char*)&file[o + 4];
+        const size_t d = o + 8;
+        if (!memcmp(type, "IHDR", 4)) {
+            if (len != 13) return false;
+            w = (int)be32(d); h = (int)be32(d + 4);
+            const int depth = file[d + 8], ctype = file[d + 9], interlace = file[d + 12];
+            if (w <= 0 || h <= 0 || w > (1 << 14) || h > (1 << 14) || depth != 8 || interlace != 0) return false;
+            ch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+            if (!ch) return false;
+            header = true;
+        } else if (!memcmp(type, "IDAT", 4)) z.insert(z.end(), file.begin() + d, file.begin() + d + len);
+        else if (!memcmp(type, "tRNS", 4)) return false;
+        else if (!memcmp(type, "IEND", 4)) break;
+        o = d + len + 4;
+    }
+    if (!header || z.empty()) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf got = raw.size();
+    if (uncompress(raw.data(), &got, z.data(), z.size()) != Z_OK || got != raw.size()) return false;
+    px.assign(stride * h, 0);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* in = &raw[(stride + 1) * y];
+        const int filter = in[0];
+        in++;
+        uint8_t* cur = &px[stride * y];
+        const uint8_t* up = y ? cur - stride : nullptr;
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= (size_t)ch ? cur[i - ch] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)ch) ? up[i - ch] : 0;
+            int pred;
+            switch (filter) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                          pred = (pa <= pb && pa <= pc) ? a : pb <= pc ? b : c; break; }
+                default: return false;
+            }
+            cur[i] = (uint8_t)(in[i] + pred);
+        }
+    }
+    return true;
+}
+/* An image file as Material::loadTexture / loadNormalMap (Material.h:128-138) would get it from stbi_load: .ppm and
+ * .png are decoded here; for a .jpg the texels the reference's decoder produced are read from the .ppm beside it
+ * (tests/golden/make_fixtures.py). A file that is not there fails like stbi_load does: the material stays plain. */
+bool load_image(const std::string& path, Texture& t) {
+    const size_t dot = path.rfind('.');
+    const std::string ext = dot == std::string::npos ? "" : path.substr(dot);
+    if (ext == ".png") return load_png(path, t.w, t.h, t.ch, t.data);
+    t.ch = 3;
+    if (ext == ".jpg" || ext == ".jpeg") return load_ppm(path.substr(0, dot) + ".ppm", t.w, t.h, t.data);
+    return load_ppm(path, t.w, t.h, t.data);
+}
 int add_ppm(orc_scene& sc, const std::string& rel) {
     Texture t;
-    if (!load_ppm(g_image_dir + "/" + rel, t.w, t.h, t.data)) return -1;
-    t.ch = 3;
+    if (!load_image(g_image_dir + "/" + rel, t)) return -1;
     sc.textures.push_back(std::move(t));
     return (int)sc.textures.size() - 1;
 }
@@ -882,6 +956,50 @@ int setup_reflexion_chamber(orc_scene& sc) {
     m.mat.kd = V3(1.f, 0.753f, 0.796f); m.mat.ks = V3(1.f, 0.753f, 0.796f); m.mat.shininess = 16;
     m.mat.transparency = 1.0f; m.mat.ior = 1.2f;
     return 0;
+}
+
+/* Scene::setup_cornell_box, Scene.h:288-466 (scene 2 of main.cpp:390, the scene of the reference's committed rendu.ppm):
+ * one pink sphere light, six textured / normal-mapped walls, a glass, a mirror and a textured sphere. Images that the
+ * reference checkout does not hold (textures/cliff.jpg, textures/stone_floor.jpg, normalMaps/sand.png) fail to load
+ * there too (Material.h:128-138: has* stays false), so their absence here is not an error; the others must load. */
+int setup_cornell_box(orc_scene& sc) {
+    Light l = make_light(V3(-1.5f, -0.75f, 1.25f), .5f);                                  /* Scene.h:305-314 */
+    l.color = V3(1.f, 0.5f, 0.75f);
+    sc.lights.push_back(l);
+    auto wall = [&](bool scale_first) {
+        SquareObj w = make_quad(V3(-1.f, -1.f, 0.f), V3(1.f, 0.f, 0.f), V3(0.f, 1.f, 0.f), 2.f, 2.f);
+        QuadPts p{w};
+        if (scale_first) { apply_matrix(p, 4, scale_matrix(V3(2.f, 2.f, 1.f))); translate(p, 4, V3(0.f, 0.f, -2.f)); }
+        else { translate(p, 4, V3(0.f, 0.f, -2.f)); apply_matrix(p, 4, scale_matrix(V3(2.f, 2.f, 1.f))); }
+        w.mat.kd = V3(1.f); w.mat.ks = V3(1.f); w.mat.shininess = 16;
+        return w;
+    };
+    bool ok = true;
+    auto need = [&](const char* rel) { int t = add_ppm(sc, rel); ok = ok && t >= 0; return t; };
+    { SquareObj w = wall(true);                                                             /* back wall, Scene.h:316-328 */
+      w.mat.nmap = need("normalMaps/n4.ppm"); w.mat.scale = 4; sc.squares.push_back(w); }
+    { SquareObj w = wall(true); QuadPts p{w}; apply_matrix(p, 4, rot_y(90.f));               /* left wall, Scene.h:330-344 */
+      w.mat.kd = V3(1.f, 0.f, 0.f); w.mat.ks = V3(1.f, 0.f, 0.f);
+      w.mat.nmap = need("normalMaps/cliff.png"); w.mat.tex = add_ppm(sc, "textures/cliff.jpg"); sc.squares.push_back(w); }
+    { SquareObj w = wall(false); QuadPts p{w}; apply_matrix(p, 4, rot_y(-90.f));             /* right wall, Scene.h:346-359 */
+      w.mat.kd = V3(0.f, 1.f, 0.f); w.mat.ks = V3(0.f, 1.f, 0.f);
+      w.mat.tex = need("sphereTextures/s5.ppm"); sc.squares.push_back(w); }
+    { SquareObj w = wall(false); QuadPts p{w}; apply_matrix(p, 4, rot_x(-90.f));             /* floor, Scene.h:361-375 */
+      w.mat.nmap = need("normalMaps/stone_floor.png"); w.mat.tex = add_ppm(sc, "textures/stone_floor.jpg"); sc.squares.push_back(w); }
+    { SquareObj w = wall(false); QuadPts p{w}; apply_matrix(p, 4, rot_x(90.f));              /* ceiling, Scene.h:377-391 */
+      w.mat.nmap = add_ppm(sc, "normalMaps/sand.png"); w.mat.tex = need("textures/sand.jpg"); sc.squares.push_back(w); }
+    { SquareObj w = wall(false); QuadPts p{w}; apply_matrix(p, 4, rot_y(180.f));             /* front wall, Scene.h:393-405 */
+      w.mat.tex = need("sphereTextures/s3.ppm"); sc.squares.push_back(w); }
+    { SphereObj g; g.c = V3(1.0f, -1.25f, 0.5f); g.r = 0.75f;                                /* glass, Scene.h:408-420 */
+      g.mat.type = MAT_GLASS; g.mat.kd = V3(1.f, 0.f, 0.f); g.mat.ks = V3(1.f, 0.f, 0.f); g.mat.shininess = 16;
+      g.mat.transparency = 0.1f; g.mat.ior = 1.2f; sc.spheres.push_back(g); }
+    { SphereObj g; g.c = V3(-1.0f, -1.25f, -0.5f); g.r = 0.75f;                              /* mirror, Scene.h:422-435 */
+      g.mat.type = MAT_MIRROR; g.mat.kd = V3(0.75f, 1.f, 1.f); g.mat.ks = V3(0.75f, 1.f, 1.f); g.mat.shininess = 16;
+      g.mat.transparency = 1.0f; g.mat.ior = 1.4f; g.mat.reflectivity = 0.5f; sc.spheres.push_back(g); }
+    { SphereObj g; g.c = V3(-0.75f, 0.f, -0.75f); g.r = 0.5f;                                /* "moon", Scene.h:437-448 */
+      g.mat.kd = V3(1.f); g.mat.ks = V3(1.f); g.mat.shininess = 10;
+      g.mat.tex = need("sphereTextures/s4.ppm"); g.mat.scale = 2; sc.spheres.push_back(g); }
+    return ok ? 0 : -2;
 }
 
 /* Scene::setup_final_scene, Scene.h:800-970. Consumes glibc rand() from seed 1
@@ -1185,6 +1303,7 @@ int orc_scene_setup(orc_scene* sc, const char* name) {
     if (n == "mesh_gorilla") return setup_mesh_scene(*sc, "gorilla18_fixed.obj.off", false);
     if (n == "mesh_cow") return setup_mesh_scene(*sc, "cow.off", true);
     if (n == "reflexion_chamber") return setup_reflexion_chamber(*sc);
+    if (n == "cornell_box") return setup_cornell_box(*sc);
     if (n.rfind("soup:", 0) == 0) return setup_soup(*sc, atoll(n.c_str() + 5));
     return -1;
 }

@@ -15,10 +15,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
 #include <fstream>
+#include <iterator>
 #include <new>
 #include <sstream>
 #include <thread>
+
+#include <zlib.h>      /* inflate, for load_png only */
 
 namespace rth {
 
@@ -55,6 +59,101 @@ bool load_ppm(const std::string& filename, Image& out) {
     }
     std::fclose(f);
     return ok;
+}
+
+/* PNG, for the .png assets of setup_cornell_box: the texels stbi_load(file, .., 0) returns for an 8-bit, non-interlaced
+ * grey / grey+alpha / RGB / RGBA file (PNG is lossless, so any conforming decoder agrees; checked against the reference's
+ * vendored decoder in tests/test_oracle_pins.py). Palette, 16-bit, interlaced and tRNS files are refused. */
+namespace {
+struct PngReader {
+    const std::vector<uint8_t>& f;
+    size_t at = 8;
+    uint32_t word(size_t o) const { return (uint32_t)f[o] << 24 | (uint32_t)f[o + 1] << 16 | (uint32_t)f[o + 2] << 8 | (uint32_t)f[o + 3]; }
+    /* next chunk: false at the end of the file or on a length that does not fit */
+    bool next(std::string& type, size_t& begin, size_t& len) {
+        if (at + 12 > f.size()) return false;
+        len = word(at);
+        if (len > f.size() - at - 12) return false;
+        type.assign((const char*)&f[at + 4], 4);
+        begin = at + 8;
+        at = begin + len + 4;
+        return true;
+    }
+};
+inline int paeth(int left, int up, int corner) {
+    const int est = left + up - corner;
+    const int dl = std::abs(est - left), du = std::abs(est - up), dc = std::abs(est - corner);
+    if (dl <= du && dl <= dc) return left;
+    return du <= dc ? up : corner;
+}
+}  // namespace
+bool load_png(const std::string& filename, Image& out) {
+    std::ifstream in(filename.c_str(), std::ios::binary);
+    if (!in) return false;
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    if (file.size() < 8 || std::memcmp(file.data(), "\x89PNG\r\n\x1a\n", 8) != 0) return false;
+    PngReader rd{file};
+    std::string type;
+    size_t begin = 0, len = 0;
+    int channels = 0;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    bool inflating = false, done = false, ok = true;
+    std::vector<uint8_t> rows;
+    while (ok && !done && rd.next(type, begin, len)) {
+        if (type == "IHDR") {
+            if (len != 13 || channels) { ok = false; break; }
+            const uint32_t w = rd.word(begin), h = rd.word(begin + 4);
+            const int depth = file[begin + 8], colour = file[begin + 9], interlace = file[begin + 12];
+            static const int per_colour[7] = {1, 0, 3, 0, 2, 0, 4};
+            channels = colour <= 6 ? per_colour[colour] : 0;
+            if (!channels || depth != 8 || interlace || !w || !h || w > 16384 || h > 16384) { ok = false; break; }
+            out.width = (int)w; out.height = (int)h; out.channels = channels;
+            rows.resize(((size_t)w * channels + 1) * h);
+            ok = inflateInit(&zs) == Z_OK;
+            inflating = ok;
+            zs.next_out = rows.data();
+            zs.avail_out = (uInt)rows.size();
+        } else if (type == "IDAT") {
+            if (!inflating) { ok = false; break; }
+            zs.next_in = &file[begin];
+            zs.avail_in = (uInt)len;
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc == Z_STREAM_END) done = true;
+            else if (rc != Z_OK || zs.avail_in) ok = false;          /* more data than the header promised */
+        } else if (type == "tRNS") ok = false;
+        else if (type == "IEND") break;
+    }
+    if (inflating) inflateEnd(&zs);
+    if (!ok || !done || zs.avail_out) return false;
+    const size_t stride = (size_t)out.width * channels;
+    out.data.resize(stride * out.height);
+    std::vector<uint8_t> zero(stride, 0);
+    for (int y = 0; y < out.height; y++) {
+        const uint8_t* src = &rows[(stride + 1) * y];
+        uint8_t* dst = &out.data[stride * y];
+        const uint8_t* above = y ? dst - stride : zero.data();
+        const uint8_t kind = *src++;
+        if (kind > 4) return false;
+        for (size_t i = 0; i < stride; i++) {
+            const bool first = i < (size_t)channels;
+            const int left = first ? 0 : dst[i - channels], up = above[i], corner = first ? 0 : above[i - channels];
+            const int guess = kind == 0 ? 0 : kind == 1 ? left : kind == 2 ? up : kind == 3 ? (left + up) / 2 : paeth(left, up, corner);
+            dst[i] = (uint8_t)(src[i] + guess);
+        }
+    }
+    return true;
+}
+/* What Material::loadTexture / loadNormalMap get from stbi_load (Material.h:128-138), by file type: PPM and PNG are read
+ * here; JPEG decoding is the caller's (its output depends on the decoder): for x.jpg the decoded texels are expected as a
+ * binary PPM x.ppm beside it (assets/img/textures/sand.ppm holds what the reference's decoder returns for its sand.jpg). */
+bool load_image(const std::string& filename, Image& out) {
+    const size_t dot = filename.rfind('.');
+    std::string ext = dot == std::string::npos ? std::string() : filename.substr(dot);
+    for (char& ch : ext) ch = (char)std::tolower((unsigned char)ch);
+    if (ext == ".png") return load_png(filename, out);
+    if (ext == ".jpg" || ext == ".jpeg") return load_ppm(filename.substr(0, dot) + ".ppm", out);
+    return load_ppm(filename, out);
 }
 
 /* ------------------------------------------------------------------ Vec3.h */
@@ -443,7 +542,7 @@ void buildBVH(const std::vector<AABB>& objectBoxes, int deepLimit, FlatTree& out
 void Scene::clear() { meshes.clear(); spheres.clear(); squares.clear(); lights.clear(); textures.clear(); sceneBvh = FlatTree(); }
 int Scene::loadImage(const std::string& relative_path) {
     Image img;
-    if (!load_ppm(g_image_dir + "/" + relative_path, img)) return -1;
+    if (!load_image(g_image_dir + "/" + relative_path, img)) return -1;
     textures.push_back(std::move(img));
     return (int)textures.size() - 1;
 }
@@ -566,6 +665,45 @@ bool Scene::setup_reflexion_chamber() {
     setColour(m.material, 1.f, 0.753f, 0.796f, 16);
     m.material.transparency = 1.0f; m.material.index_medium = 1.2f;
     m.buildTree(3);
+    buildSceneBvh();
+    return true;
+}
+
+/* Scene::setup_cornell_box, Scene.h:288-466: scene 2 of main.cpp:390 and the scene of the reference's committed rendu.ppm.
+ * textures/cliff.jpg, textures/stone_floor.jpg and normalMaps/sand.png are not in the reference checkout: there those
+ * loads fail and the material stays plain (Material.h:128-138), so a missing one is not an error here either. */
+bool Scene::setup_cornell_box() {
+    clear();
+    { Light l = pointLight(-1.5f, -0.75f, 1.25f, .5f); l.material = Vec3(1.f, 0.5f, 0.75f); lights.push_back(l); }   /* Scene.h:305-314 */
+    auto quad = [](bool scaleThenTranslate) {
+        Square s;
+        s.setQuad(Vec3(-1.f, -1.f, 0.f), Vec3(1.f, 0.f, 0.f), Vec3(0.f, 1.f, 0.f), 2.f, 2.f);
+        if (scaleThenTranslate) { s.scale(Vec3(2.f, 2.f, 1.f)); s.translate(Vec3(0.f, 0.f, -2.f)); }
+        else { s.translate(Vec3(0.f, 0.f, -2.f)); s.scale(Vec3(2.f, 2.f, 1.f)); }
+        setColour(s.material, 1.f, 1.f, 1.f, 16);
+        return s;
+    };
+    bool found = true;
+    auto must = [&](const char* rel) { const int t = loadImage(rel); found = found && t >= 0; return t; };
+    { Square s = quad(true);                                             /* back wall, Scene.h:316-328 */
+      s.material.normalMap = must("normalMaps/n4.ppm"); s.material.materialScale = 4; squares.push_back(s); }
+    { Square s = quad(true); s.rotate_y(90); setColour(s.material, 1.f, 0.f, 0.f, 16);                     /* left wall, 330-344 */
+      s.material.normalMap = must("normalMaps/cliff.png"); s.material.texture = loadImage("textures/cliff.jpg"); squares.push_back(s); }
+    { Square s = quad(false); s.rotate_y(-90); setColour(s.material, 0.f, 1.f, 0.f, 16);                   /* right wall, 346-359 */
+      s.material.texture = must("sphereTextures/s5.ppm"); squares.push_back(s); }
+    { Square s = quad(false); s.rotate_x(-90);                                                             /* floor, 361-375 */
+      s.material.normalMap = must("normalMaps/stone_floor.png"); s.material.texture = loadImage("textures/stone_floor.jpg"); squares.push_back(s); }
+    { Square s = quad(false); s.rotate_x(90);                                                              /* ceiling, 377-391 */
+      s.material.normalMap = loadImage("normalMaps/sand.png"); s.material.texture = must("textures/sand.jpg"); squares.push_back(s); }
+    { Square s = quad(false); s.rotate_y(180); s.material.texture = must("sphereTextures/s3.ppm"); squares.push_back(s); }   /* front wall, 393-405 */
+    { Sphere g; g.m_center = Vec3(1.0f, -1.25f, 0.5f); g.m_radius = 0.75f; g.material.type = RT_MAT_GLASS;                  /* 408-420 */
+      setColour(g.material, 1.f, 0.f, 0.f, 16); g.material.transparency = 0.1f; g.material.index_medium = 1.2f; spheres.push_back(g); }
+    { Sphere g; g.m_center = Vec3(-1.0f, -1.25f, -0.5f); g.m_radius = 0.75f; g.material.type = RT_MAT_MIRROR;               /* 422-435 */
+      setColour(g.material, 0.75f, 1.f, 1.f, 16); g.material.transparency = 1.0f; g.material.index_medium = 1.4f;
+      g.material.reflectivity = 0.5f; spheres.push_back(g); }
+    { Sphere g; g.m_center = Vec3(-0.75f, 0.f, -0.75f); g.m_radius = 0.5f; setColour(g.material, 1.f, 1.f, 1.f, 10);         /* 437-448 */
+      g.material.texture = must("sphereTextures/s4.ppm"); g.material.materialScale = 2; spheres.push_back(g); }
+    if (!found) return false;
     buildSceneBvh();
     return true;
 }
@@ -882,6 +1020,7 @@ bool Scene::setup(const std::string& name) {
     if (name == "mesh_gorilla") return setup_mesh_scene("gorilla18_fixed.obj.off", false);
     if (name == "mesh_cow") return setup_mesh_scene("cow.off", true);
     if (name == "reflexion_chamber") return setup_reflexion_chamber();
+    if (name == "cornell_box") return setup_cornell_box();
     if (name.rfind("soup:", 0) == 0) return setup_soup_scene(atoll(name.c_str() + 5));
     return false;
 }

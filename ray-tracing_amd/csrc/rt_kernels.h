@@ -451,7 +451,13 @@ RT_DEV void store_state(PathState* s, F3 o, F3 d, F3 thr, uint32_t slot, uint32_
 /* Radiance sums are int64 fixed point (order-independent, so frames are bit-identical for any
  * tile sharding). The reference lets NaN/Inf pass through its float sums (main.cpp:217-220); here
  * they are recorded per slot and channel (bit 3k: NaN, 3k+1: +Inf, 3k+2: -Inf) and re-applied by
- * k_resolve. Finite magnitudes >= 6e7 are treated as infinite. */
+ * k_resolve. Finite magnitudes >= 6e7 are treated as infinite, and so is a channel whose running sum leaves +-2^26
+ * (6.7e7 before the division by the sample count) -- the accumulator holds +-2^27. Contributions of magnitude >= 64
+ * take the returning form of the atomic and look at the sum they leave behind (or wrap); smaller ones do not wait
+ * for the result (the wait costs 5 % of a C3 frame if every add takes it): a million of them (2^20 per pixel and
+ * channel, each below 64) move the sum by less than 2^26, so between two looks it stays inside the accumulator
+ * and cannot wrap unseen. (Unnormalised normals out of a normal map, Scene.h:199-202, drive specular terms that far:
+ * the cornell box has a few such pixels; they are saturated in the reference's frame too.) */
 RT_DEV void accumulate(long long* acc, uint32_t* nonfinite, Counters* ctr, uint32_t slot, F3 c) {
     float v[3] = {c.x, c.y, c.z};
 #pragma unroll
@@ -464,7 +470,17 @@ RT_DEV void accumulate(long long* acc, uint32_t* nonfinite, Counters* ctr, uint3
             continue;
         }
         long long q = __double2ll_rn((double)x * RT_FIX_SCALE);
-        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(acc + 3 * (size_t)slot + k), (unsigned long long)q);
+        unsigned long long* cell = reinterpret_cast<unsigned long long*>(acc + 3 * (size_t)slot + k);
+        if (fabsf(x) >= 64.0f) {
+            const long long before = (long long)atomicAdd(cell, (unsigned long long)q);
+            const long long after = (long long)((unsigned long long)before + (unsigned long long)q);
+            const bool wrapped = ((before ^ after) & (q ^ after)) < 0;     /* both operands of one sign, the sum of the other */
+            const long long lim = 1ll << 62;                               /* 2^26 in units of 2^-36 */
+            if (wrapped || after >= lim || after <= -lim) {
+                atomicOr(nonfinite + slot, (q > 0 ? 2u : 4u) << (3 * k));
+                atomicAdd(&ctr->nonfinite, 1ull);
+            }
+        } else if (q != 0) atomicAdd(cell, (unsigned long long)q);
     }
 }
 

@@ -14,7 +14,7 @@ from helpers import psnr
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["final", "refraction", "reflexion", "reflexion_chamber", "mesh_gorilla", "mesh_cow", "soup:20000"]
+SCENES = ["final", "refraction", "reflexion", "reflexion_chamber", "cornell_box", "mesh_gorilla", "mesh_cow", "soup:20000"]
 _cache = {}
 
 
@@ -143,7 +143,7 @@ def test_ray_trace_radiance(rt, ctx, name, shadow_mode):
 
 @pytest.mark.parametrize("name,w,h,spp,depth", [("final", 64, 64, 2, 50), ("refraction", 160, 90, 4, 5),
                                                  ("mesh_gorilla", 128, 72, 2, 50), ("soup:20000", 96, 54, 4, 5),
-                                                 ("reflexion_chamber", 80, 80, 2, 12)])
+                                                 ("reflexion_chamber", 80, 80, 2, 12), ("cornell_box", 96, 96, 2, 50)])
 def test_render_frame(rt, ctx, name, w, h, spp, depth):
     hs, os_ = scene_pair(rt, ctx, name)
     aspect = w / h

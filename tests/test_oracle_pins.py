@@ -171,3 +171,34 @@ def test_image_readers_equal_stbi_load(rel):
     tex = hs.arrays()["textures"]
     if rel.endswith("n3.ppm"):
         assert any(t.shape == want.shape and np.array_equal(t, want) for t in tex), "host mirror's texels differ from stbi_load"
+
+
+CORNELL_IMAGES = ["normalMaps/n4.ppm", "normalMaps/cliff.png", "sphereTextures/s5.ppm", "normalMaps/stone_floor.png",
+                  "textures/sand.jpg", "sphereTextures/s3.ppm", "sphereTextures/s4.ppm"]      # in the order Scene.h:326-446 loads them
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_SO) and os.path.isdir("/root/reference/assets/img")), reason="needs oracle/_ref/libref.so and /root/reference")
+def test_cornell_box_images_equal_stbi_load_of_the_reference_files():
+    """setup_cornell_box's images (Scene.h:326-446): the texels the oracle's and the host mirror's readers hold -- PPM, RGBA
+    PNG (inflate + unfilter, written here) and, for sand.jpg, the decoded fixture -- equal what the reference's own
+    stb_image.h returns for the files in the reference checkout; the three images the checkout lacks stay absent."""
+    import importlib
+    R = C.CDLL(REF_SO)
+    R.ref_stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_long]
+    rt = importlib.import_module("ray-tracing_amd")
+    hs, os_ = rt.HostScene("cornell_box", 3, 12), O.Scene("cornell_box", 3, 12)
+    tex = hs.arrays()["textures"]
+    assert len(tex) == len(CORNELL_IMAGES)
+    for i, rel in enumerate(CORNELL_IMAGES):
+        path = os.path.join("/root/reference/assets/img", rel)
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        assert R.ref_stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(ch), None, 0) == 0
+        want = np.zeros((h.value, w.value, ch.value), np.uint8)
+        assert R.ref_stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(ch), want.ctypes.data_as(C.c_void_p), want.size) == 0
+        assert ch.value == (4 if rel.endswith(".png") else 3)
+        assert tex[i].shape == want.shape and np.array_equal(tex[i], want), f"host mirror: {rel}"
+        got = os_.texture(i)
+        assert got.shape == want.shape and np.array_equal(got, want), f"oracle: {rel}"
+    for rel in ("textures/cliff.jpg", "textures/stone_floor.jpg", "normalMaps/sand.png"):
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        assert R.ref_stbi_load(os.path.join("/root/reference/assets/img", rel).encode(), C.byref(w), C.byref(h), C.byref(ch), None, 0) == -1
