@@ -179,7 +179,12 @@ int rt_begin_frame(rt_ctx*, const rt_render_params*);
 /* Queues the pixels [x0,x0+w) x [y0,y0+h) (the per-pixel ThreadPool tasks of main.cpp:210-225).
  * Asynchronous: the work runs at the next rt_download_framebuffer / rt_resolve_device / rt_flush. */
 int rt_render_tile(rt_ctx*, int x0, int y0, int w, int h);
-/* Runs all queued tiles to completion on the device. */
+/* Runs all queued tiles to completion on the device.
+ * Queue capacities: a batch of B path states can append at most 2 B children (two per glass hit) and B diffuse records,
+ * which is what the queues hold, and the path-state stack holds batch x (max_depth + 3): by construction they cannot
+ * overflow. The kernels nevertheless bound every append (a state that does not fit is dropped, never written out of
+ * range) and the host compares the counters with the capacities after every iteration: RT_ERR_LIMIT ("queue overflow")
+ * would report a dropped state instead of returning a frame that misses it. */
 int rt_flush(rt_ctx*);
 /* pixel_color /= nsamples (main.cpp:219) for the whole image, rows top to bottom, into host memory.
  * prim_id (optional): 2 x uint32 per pixel = (object ordinal, triangle index) of sample 0's primary hit,
