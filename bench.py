@@ -9,10 +9,14 @@ assembled with one RCCL all-gather of packed tile slabs -- strong scaling.
 
 Prints ONE JSON line on rank 0 (the repo's bench contract):
   value        rays of all ranks / max-over-ranks wall time of the timed steps
-  roofline     for the dominant kernel, k_shadow. What binds it is VALU issue, not HBM: `achieved` = executed
-               VALU lane-operations per second (SQ_THREAD_CYCLES_VALU per ray from the PMC pass over this very
-               frame, profiles/c5_k_shadow_pmc.json, x the rays of a launch / the launch duration measured live
-               with HIP events inside the library), `peak` = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz. Beside it:
+  roofline     for the dominant kernel, k_shadow. It is bound on-chip, by two resources at once (experiments/README.md,
+               "What binds k_shadow"): the vector L1's one lane-access per clock per CU (`l1`: the kernel's four
+               16-byte loads per lane and node step sit on that ceiling) and, 15 % behind it, VALU issue. `bound` =
+               "valu": `achieved` = executed VALU lane-operations per second (SQ_THREAD_CYCLES_VALU per ray from the PMC
+               pass over this very frame, profiles/c5_k_shadow_pmc.json, x the rays of a launch / the launch duration
+               measured live with HIP events inside the library), `peak` = the f32 vector peak of MI355X_MICROARCH.md
+               (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s); `slow_class_rate` is what the instruction
+               classes the kernel mostly consists of can reach (half of it). Beside it:
                `hbm` (counter traffic vs 8 TB/s), `executed_bytes` (node and triangle records the walk requested
                vs the L2 peak) and `reference_algorithm_equiv_GBps` (SURVEY 8(d)'s bytes per ray of the
                reference's exhaustive traversal -- a speed-up figure, it exceeds the HBM peak because the GPU
@@ -36,7 +40,15 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0          # ... aggregate L2 bandwidth
-VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12     # one wave64 VALU instruction per 4 cycles per SIMD: 39.3 T lane-ops/s
+# VALU lane-operation peak: MI355X_MICROARCH.md prices a wave64 v_fma_f32 at 2 cycles per SIMD (f32 vector peak 157.3 TFLOP/s
+# = 78.6 T lane-FMA/s = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz). tools/micro/valu_rate.hip (profiles/r02_micro_valu_rate.txt)
+# measures 66 T for v_add_u32, 53 T for v_fma_f32 and 35-38 T for the min/max/perm/cvt/cmp/select class (4 cycles per
+# instruction) that most of k_shadow consists of: VALU_SLOW_CLASS is that second rate, reported beside the peak.
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+VALU_SLOW_CLASS_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# Vector L1: one lane-access (one lane x one load instruction) per clock per CU for divergent loads, measured
+# (tools/micro/l1_rate.hip, profiles/r02_micro_l1_rate.txt: 0.99 whatever the table size and the width of the load).
+L1_LANE_ACCESS_PEAK_G = 256 * 1.0 * 2.4e9 / 1e9
 PER_RAY_FILE = os.path.join(ROOT, "profiles", "c5_per_ray.json")
 PMC_FILE = os.path.join(ROOT, "profiles", "c5_k_shadow_pmc.json")
 CHECKSUM_FILE = os.path.join(ROOT, "profiles", "c5_checksum.json")   # frame checksums of the plain reference-order traversal
@@ -249,8 +261,16 @@ def main():
                     "bound": "valu", "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 3), "unit": "Tlane-op/s",
                     "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": round(hbm_bytes),
                     "valu_lane_ops_per_ray": round(ops_per_ray, 1),
-                    "lanes_active_per_valu_inst": round(pmc["SQ_THREAD_CYCLES_VALU_per_launch"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU_per_launch"]), 4),
-                    "valu_busy_of_wave_slots": round(pmc["SQ_ACTIVE_INST_VALU_per_launch"] * pmc.get("waves_per_simd", 4) / pmc["SQ_WAVE_CYCLES_per_launch"], 4),
+                    "lanes_active_per_valu_inst": round(pmc["SQ_THREAD_CYCLES_VALU_per_launch"] / (64.0 * pmc["SQ_INSTS_VALU_per_launch"]), 4),
+                    "valu_insts_per_ray": round(pmc["SQ_INSTS_VALU_per_launch"] / pmc["rays_per_launch"], 1),
+                    "frac_of_slow_class_rate": round(achieved / VALU_SLOW_CLASS_TLANEOPS, 4),
+                    "slow_class_rate": round(VALU_SLOW_CLASS_TLANEOPS, 3),
+                    # the co-limit: k_shadow's four 16-byte loads per lane and node step against the vector L1's one lane-access per clock
+                    "l1": {"lane_accesses_per_ray": round(pmc["TCP_TOTAL_CACHE_ACCESSES_sum_per_launch"] / pmc["rays_per_launch"], 1),
+                           "achieved": round(pmc["TCP_TOTAL_CACHE_ACCESSES_sum_per_launch"] / pmc["rays_per_launch"] * rays_per_launch / avg_s / 1e9, 1),
+                           "ceiling": round(L1_LANE_ACCESS_PEAK_G, 1), "unit": "G lane-accesses/s",
+                           "ratio": round(pmc["TCP_TOTAL_CACHE_ACCESSES_sum_per_launch"] / pmc["rays_per_launch"] * rays_per_launch / avg_s / 1e9 / L1_LANE_ACCESS_PEAK_G, 4),
+                           "note": "ceiling measured for divergent loads (tools/micro/l1_rate.hip); lanes of one instruction that want the same line are served together, so a kernel with partly coherent lanes can read a little above it"},
                     "hbm": {"achieved": round(hbm_bytes / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(hbm_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4)},
                     "executed_bytes": {"bytes_per_ray": round(ex_bpr, 1), "achieved": round(ex_bpr * rays_per_launch / avg_s / 1e9, 1),
