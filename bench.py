@@ -139,10 +139,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on one card, collectives over gloo
+    if os.environ.get("RT_BENCH_ONE_DEVICE"):
+        local_rank = int(os.environ["RT_BENCH_ONE_DEVICE"])
     torch.cuda.set_device(local_rank)
     rt = importlib.import_module("ray-tracing_amd")
     rtd = importlib.import_module("ray-tracing_amd.dist")
-    rtd.init("nccl", local_rank)          # RCCL; no-op for one rank
+    rtd.init(os.environ.get("RT_BENCH_BACKEND", "nccl"), local_rank)          # RCCL; no-op for one rank
 
     W, H = args.width, args.height
     name = f"soup:{args.ntris}"
