@@ -70,6 +70,7 @@ RT_DEV int lds_index(int k, int stride) { return k * stride; }
 #define TOP_ITEM 0x20000000u        /* on a record index: not a triangle record but a top-level object ordinal (leaf of the sub-tree over the objects of a top-level leaf) */
 #define LINK_SENTINEL (-1)          /* on a lane's stack: below this entry lies the walk of a top-level leaf's sub-tree (scene frame), above it a mesh walk */
 #define TRI_SUB 0x40000000u         /* on a record index: a run inside a fat leaf (reached through the leaf's sub-tree) */
+#define TRI_EXACT 0x10000000u       /* on a pending record index (quantised walk): the record passed the plane filter (tri_maybe), the reference's test is still to run */
 #define TRI_LEAF_END 2u             /* record word 2.w: bit 0 = last of its run, bit 1 = last of its reference leaf */
 RT_DEV uint32_t leaf_first(int link) { return (uint32_t)(-2 - link); }
 
@@ -809,6 +810,9 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
 #ifndef RT_TRI_MIN
 #define RT_TRI_MIN 24         /* pending leaves that make a triangle round worthwhile */
 #endif
+#ifndef RT_EXACT_MIN
+#define RT_EXACT_MIN 8        /* records that passed the plane filter and make a round of the reference's triangle test worthwhile */
+#endif
 #ifndef RT_TRI_MORE
 #define RT_TRI_MORE 16        /* pending leaves that justify another triangle step in the same round */
 #endif
@@ -1153,6 +1157,28 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
     s.link = link;
     if (!can_walk(s, sc.top_cap)) s.st = ST_BLOCKED;
 }
+/* A filter in front of the reference's triangle test. Triangle::getIntersection costs about 300 instructions (three
+ * cross products, three correctly rounded square roots and divisions) and nine in ten of the triangles a shadow ray
+ * meets are misses, but the lanes of a wave miss at different times, so an early exit inside the test saves nothing.
+ * The filter computes the plane point P exactly as the test does (same operations, same bits) and looks at two affine
+ * coordinates of it, u = g1.(P - c0), v = g2.(P - c0) (g1, g2: the dual basis of the triangle's edges, 16-bit floats in
+ * slot 7 of the record): a point the reference accepts lies within the record's hit excursion e of the triangle
+ * (rtgpu.hip, tri_excursion), hence has u, v >= -m and u + v <= 1 + m with the margin m the upload derives from e, the
+ * rounding of g1, g2 to 8 bits and of this evaluation (m = inf where there is no bound: nothing is rejected). NaNs
+ * compare false and pass (the reference lets a NaN sum pass, Triangle.h:105). What passes is tested by the reference's
+ * arithmetic in a round of its own (TRI_EXACT), with the lanes that also have a candidate. */
+RT_DEV bool tri_maybe(const Ray& r, float4 q0, float4 q3, uint4 q7) {
+    const F3 c0 = f3(q0.x, q0.y, q0.z), n = f3(q3.x, q3.y, q3.z);
+    const float dn = dot(r.d, n);
+    if (dn == 0) return false;                                   /* Triangle.h:49-53, as in tri_test */
+    const float t = (q0.w - dot(r.o, n)) / dn;                   /* Triangle.h:59 */
+    const F3 v = sub(add(r.o, mul(t, r.d)), c0);                 /* Triangle.h:61 */
+    const F3 g1 = f3(__uint_as_float(q7.x << 16), __uint_as_float(q7.x & 0xFFFF0000u), __uint_as_float(q7.y << 16));
+    const F3 g2 = f3(__uint_as_float(q7.y & 0xFFFF0000u), __uint_as_float(q7.z << 16), __uint_as_float(q7.z & 0xFFFF0000u));
+    const float m = __uint_as_float(q7.w << 16);
+    const float a = dot(v, g1), b = dot(v, g2);
+    return !(a < -m || b < -m || a + b > 1.0f + m);
+}
 /* one triangle of a leaf of the quantised walk; the first one brings the reference's test of the leaf's own box along.
  * SUB: a fat leaf that passes hands over to its sub-tree (pushed; words 24-25 of the record), whose runs are then
  * reached like leaves but without a box of their own to test. */
@@ -1160,7 +1186,8 @@ template <bool SUB>
 RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt, const WideStack& w) {
     const uint32_t pos = s.tri_pos & (SUB ? ~(TRI_NEW | TRI_SUB) : ~TRI_NEW);
     const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)pos;
-    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const float4 q0 = q[0], q3 = q[3];
+    const uint4 q7 = *reinterpret_cast<const uint4*>(q + 7);     /* the filter's planes, its margin and the record's flags */
     bool reached = true;
     if ((s.tri_pos & TRI_NEW) && !(SUB && (s.tri_pos & TRI_SUB))) {
         float4 b0 = q[4], b1 = q[5];                               /* the leaf's reference box rides in the same line */
@@ -1171,11 +1198,21 @@ RT_DEV void shadow_quant_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt
             if (__float_as_uint(gate.y) != 0u) { wpush(w, s.msp, __float_as_int(gate.x)); reached = false; }
         }
     }
-    s.tri_pos = (!reached || __float_as_uint(q2.w) != 0u) ? TRI_NONE : pos + 1;
+    if (reached && tri_maybe(s.r, q0, q3, q7)) { s.tri_pos = pos | TRI_EXACT; return; }    /* a candidate: stays pending (the lane may go on walking, see can_walk) */
+    s.tri_pos = (!reached || (q7.w >> 16) != 0u) ? TRI_NONE : pos + 1;
+    if (s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link) | TRI_NEW; s.link = LINK_NONE; }
+    s.st = can_walk(s, sc.top_cap) ? ST_MESH : ST_BLOCKED;
+}
+/* the reference's test on a record that passed the filter */
+RT_DEV void shadow_quant_exact_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
+    const uint32_t pos = s.tri_pos & ~TRI_EXACT;
+    const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)pos;
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    s.tri_pos = __float_as_uint(q2.w) != 0u ? TRI_NONE : pos + 1;
     if (s.tri_pos == TRI_NONE && s.link < 0 && s.link != LINK_NONE) { s.tri_pos = leaf_first(s.link) | TRI_NEW; s.link = LINK_NONE; }
     s.st = can_walk(s, sc.top_cap) ? ST_MESH : ST_BLOCKED;
     float t, w0, w1, w2;
-    if (reached && tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
+    if (tri_test(s.r, q0, q1, q2, q3, t, w0, w1, w2) && t <= s.bound) shadow_on_hit(sc, s, cnt);
 }
 
 /* Scene::sampleSphereLight's sample position + Scene::isInShadow's ray (Scene.h:115-126,161-164) for
@@ -1425,7 +1462,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             if (walking) { if (QUANT) shadow_quant_step<SUB, TOPSUB>(sc, s, wst); else shadow_node_step(sc, s, stk, stride); }
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_nodeph += k_t1 - k_t0; k_t0 = k_t1; }
-        /* triangle phase: worth a round once enough lanes have a leaf pending, or when the walkers are the minority */
+        /* triangle phase: worth a round once enough lanes have a leaf pending, or when the walkers are the minority.
+         * Quantised walk: the rounds run the leaf's box test and the plane filter (tri_maybe); the records that pass
+         * wait (TRI_EXACT) for a round of the reference's test, which starts once RT_EXACT_MIN lanes hold one or the
+         * walkers are the minority. */
         {
             const bool pend = s.st >= ST_MESH && s.tri_pos != TRI_NONE;
             const int np = __popcll(__builtin_amdgcn_ballot_w64(pend)), nw = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_MESH));
@@ -1434,12 +1474,21 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         }
 #pragma unroll 1
         for (int k = 0; k < RT_TRI_STEPS; k++) {
-            bool pending = s.st >= ST_MESH && s.tri_pos != TRI_NONE;
+            bool pending = s.st >= ST_MESH && s.tri_pos != TRI_NONE && !(QUANT && (s.tri_pos & TRI_EXACT));
             const int np = __popcll(__builtin_amdgcn_ballot_w64(pending));
             if (np == 0) break;
             if (k > 0 && np < RT_TRI_MORE && __builtin_amdgcn_ballot_w64(s.st == ST_MESH) != 0ull) break;   /* a thin follow-up round only if nobody could walk instead */
             if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wt++; if (pending) { c_tri++; if (s.ts & TS_MODE) c_m1t++; } }
             if (pending) { if (QUANT) shadow_quant_tri_step<SUB>(sc, s, cnt, wst); else shadow_tri_step(sc, s, cnt); }
+        }
+        if (QUANT) {
+            const bool cand = s.st >= ST_MESH && s.tri_pos != TRI_NONE && (s.tri_pos & TRI_EXACT);
+            const int nc = __popcll(__builtin_amdgcn_ballot_w64(cand));
+            const int nw = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_MESH)), nb = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_BLOCKED));
+            if (nc > 0 && (nc >= RT_EXACT_MIN || nw <= nb)) {
+                if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wtop++; if (cand) c_other++; }
+                if (cand) shadow_quant_exact_step(sc, s, cnt);
+            }
         }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_triph += k_t1 - k_t0; }
     }

@@ -516,6 +516,68 @@ double tri_excursion(const H3& c0, const H3& c1, const H3& c2, float area_f) {
     return 2.0 * rho;
 }
 
+/* The plane filter of the shadow walk (rt_kernels.h, tri_maybe): g1 = (e2 x n) / |n|^2, g2 = (n x e1) / |n|^2 with
+ * e1 = c1 - c0, e2 = c2 - c0, n = e1 x e2 give u = g1.(P - c0), v = g2.(P - c0) with P = c0 + u e1 + v e2 + (a multiple
+ * of n); on the triangle u, v >= 0 and u + v <= 1, and |grad u| = |g1|, |grad v| = |g2|, |grad (u+v)| <= |g1| + |g2|.
+ * A point within e (the record's hit excursion) of the triangle therefore has u, v >= -e G and u + v <= 1 + e G,
+ * G = |g1| + |g2|. The kernel evaluates with g1, g2 rounded to 16-bit floats (8 significant bits: each component off by
+ * at most 2^-8 of itself, the dot product by at most 2^-8 sqrt(3) |P - c0| |g|, |P - c0| <= l + e with l the longest
+ * side) and in float (P - c0 and the products and sums: a few units of 2^-24 times (|c|_max + l + e) |g|_1). The margin
+ * m covers the three with room, is rounded up to a 16-bit float, and is infinite where e is (no bound) or where the
+ * triangle is too degenerate for the planes to mean anything. Slot 7 = (g1.x | g1.y << 16, g1.z | g2.x << 16,
+ * g2.y | g2.z << 16, m | flags << 16), each value the upper half of its float. */
+uint32_t half_float_nearest(double v) {
+    float f = (float)v;
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    if ((b & 0x7F800000u) == 0x7F800000u) return b >> 16;              /* inf / NaN as they are */
+    b += 0x7FFFu + ((b >> 16) & 1u);                                  /* round to nearest even on bit 16 */
+    return b >> 16;
+}
+uint32_t half_float_up(double v) {                                    /* v >= 0: the next 16-bit float at or above it */
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafter(f, INFINITY);
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    if ((b & 0x7F800000u) == 0x7F800000u) return 0x7F80u;
+    if (b & 0xFFFFu) b += 0x10000u;
+    if ((b & 0x7F800000u) == 0x7F800000u) return 0x7F80u;
+    return b >> 16;
+}
+uint4 filter_planes(const float4& q0, const float4& q1, const float4& q2, float exc, uint32_t flags) {
+    const double c0[3] = {q0.x, q0.y, q0.z}, c1[3] = {q1.x, q1.y, q1.z}, c2[3] = {q2.x, q2.y, q2.z};
+    double e1[3], e2[3], n[3], g1[3], g2[3];
+    for (int k = 0; k < 3; k++) { e1[k] = c1[k] - c0[k]; e2[k] = c2[k] - c0[k]; }
+    auto cross3 = [](const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+    cross3(e1, e2, n);
+    const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    const uint32_t pass_all = 0x7F80u | (flags << 16);                /* margin = inf: the filter rejects nothing */
+    if (!(exc < 1e30f) || !(nn > 1e-280) || !(nn < 1e280)) return make_uint4(0u, 0u, 0u, pass_all);
+    cross3(e2, n, g1);
+    cross3(n, e1, g2);
+    double G1 = 0, G2 = 0, G1s = 0, G2s = 0, cmax = 0, l = 0;
+    for (int k = 0; k < 3; k++) {
+        g1[k] /= nn; g2[k] /= nn;
+        G1 += g1[k] * g1[k]; G2 += g2[k] * g2[k];
+        G1s += std::fabs(g1[k]); G2s += std::fabs(g2[k]);
+        cmax = std::max(cmax, std::max(std::fabs(c0[k]), std::max(std::fabs(c1[k]), std::fabs(c2[k]))));
+    }
+    auto side = [](const double* a, const double* b) { return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2])); };
+    l = std::max(side(c0, c1), std::max(side(c1, c2), side(c2, c0)));
+    const double G = std::sqrt(G1) + std::sqrt(G2), e = (double)exc;
+    const double u24 = 1.0 / 16777216.0;
+    double m = e * G                                                 /* where an accepted point can lie */
+             + (l + e) * G * 1.7320508 / 256.0 * 2.0                 /* g1, g2 rounded to 8 bits (u + v: both) */
+             + 16.0 * u24 * (cmax + l + e) * (G1s + G2s)             /* float evaluation */
+             + 1e-6;
+    m *= 1.05;
+    if (!(m < 1e30) || !(G < 1e30)) return make_uint4(0u, 0u, 0u, pass_all);
+    uint32_t h[6] = {half_float_nearest(g1[0]), half_float_nearest(g1[1]), half_float_nearest(g1[2]),
+                     half_float_nearest(g2[0]), half_float_nearest(g2[1]), half_float_nearest(g2[2])};
+    for (uint32_t v : h) if ((v & 0x7F80u) == 0x7F80u) return make_uint4(0u, 0u, 0u, pass_all);      /* a component beyond the 16-bit float range */
+    return make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), half_float_up(m) | (flags << 16));
+}
+
 /* what the accepted hits below one child of a mesh node stay inside: the union, over its triangle records, of the
  * record's box grown by its excursion (+ a floor for the rounding of P = o + t*d itself); unbounded = some record
  * below has no bound */
@@ -904,7 +966,7 @@ int check_desc(rt_ctx* c, const rt_scene_desc* d) {
         }
     }
     if (d->top_depth > 60 || d->n_top_leaves > 4000) return fail(c, RT_ERR_LIMIT, "top-level tree too deep or too wide (k_shadow packs its top-level state)");
-    if (d->n_tris > 0x1FFFFFF0ll || d->n_mesh_nodes > 0x7FFFFFF0ll || d->n_mesh_leaves > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "scene too large for 32-bit links");
+    if (d->n_tris > 0x0FFFFFF0ll || d->n_mesh_nodes > 0x7FFFFFF0ll || d->n_mesh_leaves > 0x7FFFFFF0ll) return fail(c, RT_ERR_LIMIT, "scene too large for 32-bit links");
     return RT_OK;
 }
 
@@ -1212,6 +1274,16 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
             for (int p : run_last) flag_record(g0 + (size_t)p, 1u);
             flag_record(g0 + n - 1, 3u);
         }
+        /* slot 7 of every record: the plane filter of the shadow walk (rt_kernels.h, tri_maybe) and a copy of the flags */
+        parallel_for(m.tri_count, [&](int64_t j_lo, int64_t j_hi) {
+            for (int64_t j = j_lo; j < j_hi; j++) {
+                float4* q = &tri[RT_TRI_STRIDE * (size_t)(m.tri_first + j)];
+                uint32_t flags;
+                memcpy(&flags, &q[2].w, 4);
+                const uint4 f = filter_planes(q[0], q[1], q[2], texc[(size_t)j], flags);
+                memcpy(&q[7], &f, 16);
+            }
+        });
         meshes[mi].root = glob(m.root);
         meshes[mi].material = m.material;
         meshes[mi].amax = amax;
