@@ -203,6 +203,10 @@ int rt_uses_quantised_shadow_nodes(const rt_ctx*);
  * (Triangle.h:101-107, barycentric sum in [0.9999, 1.00001]) can lie; infinity if the acceptance test gives no
  * bound (degenerate triangles). Tests hold it against the oracle's accepted hits. */
 double rt_hit_excursion(const float v0[3], const float v1[3], const float v2[3], float amax);
+/* No counterpart in the reference: the conservative plane filter the shadow walk runs in front of Triangle::getIntersection
+ * (Triangle.h:86-121) on scenes with many objects, evaluated on the host for one triangle and one ray (1 = the triangle
+ * goes on to the reference's test, 0 = rejected). Host only; for the tests that hold it against what the oracle accepts. */
+int rt_filter_passes(const float v0[3], const float v1[3], const float v2[3], float amax, const float origin[3], const float direction[3]);
 
 /* Fine-grained seams, host arrays in and out:
  * Scene::computeIntersection (Scene.h:84-88) on n rays (origin, direction as given to Ray()). */

@@ -117,7 +117,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
 # every symbol include/rtgpu.h and include/rthost.h declare
 EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame",
            "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_get_stats",
-           "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion",
+           "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion", "rt_filter_passes",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
            "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_build_mode", "rth_scene_desc",
            "rth_ray_trace_from_camera", "rth_write_ppm", "rth_load_off", "rth_scene_save", "rth_scene_load"]
@@ -156,6 +156,8 @@ def lib():
     L.rt_uses_quantised_shadow_nodes.argtypes = [vp]
     L.rt_hit_excursion.argtypes = [vp, vp, vp, C.c_float]
     L.rt_hit_excursion.restype = C.c_double
+    L.rt_filter_passes.argtypes = [vp, vp, vp, C.c_float, vp, vp]
+    L.rt_filter_passes.restype = C.c_int
     L.rt_intersect.argtypes = [vp, vp, vp, i64, vp]
     L.rt_occluded.argtypes = [vp, vp, vp, i64, vp]
     L.rt_trace.argtypes = [vp, vp, vp, vp, vp, i64, C.POINTER(RenderParams), vp]
