@@ -176,6 +176,13 @@ int rt_upload_scene(rt_ctx*, const rt_scene_desc*);
 int rt_set_camera(rt_ctx*, const rt_camera*);
 /* Starts a frame: allocates/clears the img_w x img_h accumulator (std::vector<Vec3> image, main.cpp:203). */
 int rt_begin_frame(rt_ctx*, const rt_render_params*);
+/* Progressive accumulation, the part of SURVEY 8(f).4 that needs no GL (the reference redraws its GL preview while a frame
+ * is being traced, main.cpp:154-177, and writes the PPM at the end; this lets a viewer show the frame after every pass).
+ * Ends the current pass (runs what is queued) and opens the next one on the SAME accumulators: the tiles queued after it
+ * add more_spp samples per pixel numbered on from the samples already taken, and every resolve divides by the total so
+ * far. Passes of 4 + 4 + 8 samples leave the bits of one 16-sample frame (same sample numbers, same counter-RNG streams,
+ * order-independent sums). Image size, camera and the other parameters stay those of rt_begin_frame. */
+int rt_continue_frame(rt_ctx*, int32_t more_spp);
 /* Queues the pixels [x0,x0+w) x [y0,y0+h) (the per-pixel ThreadPool tasks of main.cpp:210-225).
  * Asynchronous: the work runs at the next rt_download_framebuffer / rt_resolve_device / rt_flush. */
 int rt_render_tile(rt_ctx*, int x0, int y0, int w, int h);

@@ -115,7 +115,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
                       ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", "<f4"), ("v", "<f4")])
 
 # every symbol include/rtgpu.h and include/rthost.h declare
-EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame",
+EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame", "rt_continue_frame",
            "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_get_stats",
            "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion", "rt_filter_passes",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
@@ -148,6 +148,7 @@ def lib():
     L.rt_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
     L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.rt_begin_frame.argtypes = [vp, C.POINTER(RenderParams)]
+    L.rt_continue_frame.argtypes = [vp, i32]
     L.rt_render_tile.argtypes = [vp, i32, i32, i32, i32]
     L.rt_flush.argtypes = [vp]
     L.rt_download_framebuffer.argtypes = [vp, vp, vp, C.POINTER(Stats)]
@@ -394,6 +395,10 @@ class Context:
     def begin_frame(self, params):
         self.params = params
         self._check(self.L.rt_begin_frame(self.h, C.byref(params)), "rt_begin_frame")
+
+    def continue_frame(self, more_spp):
+        """Progressive accumulation: the tiles queued from here on add more_spp samples per pixel to the open frame."""
+        self._check(self.L.rt_continue_frame(self.h, int(more_spp)), "rt_continue_frame")
 
     def render_tile(self, x0, y0, w, h):
         self._check(self.L.rt_render_tile(self.h, x0, y0, w, h), "rt_render_tile")

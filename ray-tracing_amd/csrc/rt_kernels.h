@@ -53,6 +53,7 @@ struct CameraD { double pinv[16], mvinv[16]; float eye[3]; float pad; };
 struct FrameD {
     int32_t img_w, img_h, spp, max_depth, light_samples, shadow_mode, jitter;
     uint32_t seed;
+    int32_t sample_base;    /* progressive accumulation (rt_continue_frame): samples per pixel of the earlier passes; this pass renders sample_base .. sample_base + spp - 1 */
 };
 struct HitD { int exists; float t; int obj; int tri; F3 n; F3 pos; float u, v; int mat; };
 
@@ -556,7 +557,7 @@ RT_DEV void locate_sample(const TileD* tiles, int n_tiles, const FrameD& fr, uns
     TileD t = tiles[lo];
     unsigned long long local = k - t.first;
     unsigned long long pix = local / (unsigned)fr.spp;
-    s = (int)(local % (unsigned)fr.spp);
+    s = fr.sample_base + (int)(local % (unsigned)fr.spp);
     x = t.x0 + (int)(pix % (unsigned)t.w);
     y = t.y0 + (int)(pix / (unsigned)t.w);
 }

@@ -1865,6 +1865,7 @@ static int check_params(rt_ctx* c, const rt_render_params* p) {
 static void set_frame(rt_ctx* c, const rt_render_params* p) {
     c->fr.img_w = p->img_w; c->fr.img_h = p->img_h; c->fr.spp = p->spp; c->fr.max_depth = p->max_depth;
     c->fr.light_samples = p->light_samples; c->fr.shadow_mode = p->shadow_mode; c->fr.jitter = p->jitter; c->fr.seed = p->seed;
+    c->fr.sample_base = 0;
 }
 
 int rt_begin_frame(rt_ctx* c, const rt_render_params* p) {
@@ -1895,6 +1896,26 @@ int rt_begin_frame(rt_ctx* c, const rt_render_params* p) {
     c->queued_samples = 0;
     memset(&c->stats, 0, sizeof(c->stats));
     c->has_frame = true;
+    return RT_OK;
+}
+
+/* progressive accumulation: more samples into the accumulators of the frame that is open */
+int rt_continue_frame(rt_ctx* c, int32_t more_spp) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_continue_frame before rt_begin_frame");
+    if (more_spp < 1 || (long long)c->fr.sample_base + c->fr.spp + more_spp > 0x00FFFFFFll) return fail(c, RT_ERR_ARG, "rt_continue_frame: samples per pixel out of range");
+    int rc = rt_flush(c);                                   /* what is queued belongs to the pass that ends here */
+    if (rc) return rc;
+    if (!c->subs.empty()) {
+        rc = on_all(c, [&](rt_ctx* q) { return rt_continue_frame(q, more_spp); });
+        if (rc) return rc;
+        for (auto& t : c->sub_tiles) t.clear();
+    } else {
+        c->tiles.clear();
+        c->queued_samples = 0;
+    }
+    c->fr.sample_base += c->fr.spp;
+    c->fr.spp = more_spp;
     return RT_OK;
 }
 
@@ -2016,7 +2037,7 @@ int rt_resolve_device(rt_ctx* c, void* d_rgb) {
     if (rc) return rc;
     uint32_t npix = (uint32_t)((size_t)c->fr.img_w * c->fr.img_h);
     hipLaunchKernelGGL(k_resolve, dim3((npix * 3 + 255) / 256), dim3(256), 0, c->stream, static_cast<const long long*>(c->acc.p),
-                       static_cast<const uint32_t*>(c->nf.p), npix, c->fr.spp, static_cast<float*>(d_rgb));
+                       static_cast<const uint32_t*>(c->nf.p), npix, c->fr.sample_base + c->fr.spp, static_cast<float*>(d_rgb));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
@@ -2256,7 +2277,7 @@ int rt_camera_rays(rt_ctx* c, const rt_render_params* p, int x0, int y0, int w, 
     size_t n = (size_t)w * h * p->spp;
     if (n > 0x3FFFFFFFull) return fail(c, RT_ERR_LIMIT, "too many rays");
     HIP_TRY(c, hipSetDevice(c->device));
-    FrameD fr;
+    FrameD fr{};
     fr.img_w = p->img_w; fr.img_h = p->img_h; fr.spp = p->spp; fr.max_depth = p->max_depth; fr.light_samples = p->light_samples;
     fr.shadow_mode = p->shadow_mode; fr.jitter = p->jitter; fr.seed = p->seed;
     DevBuf a, b;

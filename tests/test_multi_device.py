@@ -41,6 +41,17 @@ def test_two_sub_contexts_give_the_one_device_frame(ctx, name, depth):
         got2, _, _ = multi.render(cam, p, tiles=some)
         want2, _, _ = ctx.render(cam, p, tiles=some)
         assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+        # progressive passes (rt_continue_frame) across the sub-contexts: 1 + 1 samples = the 2-sample frame
+        p1 = rt.make_params(100, 72, spp=1, max_depth=depth, light_samples=35, shadow_mode=0, jitter=1, seed=2)
+        multi.set_camera(cam)
+        multi.begin_frame(p1)
+        for t in rt.interleaved_tiles(100, 72):
+            multi.render_tile(*t)
+        multi.continue_frame(1)
+        for t in rt.interleaved_tiles(100, 72):
+            multi.render_tile(*t)
+        got3, gprim3, _ = multi.download()
+        assert np.array_equal(got3.view(np.uint32), want.view(np.uint32)) and np.array_equal(gprim3, wprim)
         # the seams on explicit rays run on the first device
         org, dirs = multi.camera_rays(p, 10, 10, 8, 8)
         assert np.array_equal(multi.intersect(org, dirs), ctx.intersect(org, dirs))
