@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--cpu-crop", type=int, default=256, help="side of the centred crop the CPU baseline renders (SURVEY 8(d): 256)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the C3/C4 frames")
-    ap.add_argument("--tree-mode", type=int, default=0, help="1: binned-SAH mesh tree (free topology: NOT the reference's answers, SURVEY 8(f).2); never the default")
+    ap.add_argument("--tree-mode", type=int, default=0, help="1: binned-SAH mesh tree, 2: linear BVH built on the GPU (free topology: NOT the reference's answers, SURVEY 8(f).2); never the default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

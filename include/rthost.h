@@ -67,6 +67,9 @@ struct AABB {                 /* AccelerationStruct.h:11-70 */
 };
 
 /* One flattened BVH (inner nodes with both child boxes, leaves, leaf items). */
+/* thrown by the tree builders that can fail (the GPU builder: no device, tree too deep); the C facade turns it into its code */
+struct BuildError { int code; std::string message; };
+
 struct FlatTree {
     std::vector<rt_bvh_node> nodes;
     std::vector<rt_bvh_leaf> leaves;
@@ -196,7 +199,7 @@ void set_asset_dir(const std::string& dir);
 void set_image_dir(const std::string& dir);            /* stands for the reference's "assets/img/" */
 
 /* BVH_Node::buildBVH for triangles (AccelerationStruct.cpp:91-113,151-195). */
-void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out, int tree_mode = 0);   /* tree_mode 1: binned SAH, not the reference's tree */
+void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& triangles, int deepLimit, FlatTree& out, int tree_mode = 0);   /* tree_mode 1: binned SAH, 2: built on the GPU (throws BuildError if that fails); neither is the reference's tree */
 /* BVH_Node::buildBVH for objects (AccelerationStruct.cpp:115-148,197-243). */
 void buildBVH(const std::vector<AABB>& objectBoxes, int deepLimit, FlatTree& out);
 
@@ -226,7 +229,9 @@ int rth_add_sphere(rth_scene*, const float center[3], float radius, const rt_mat
 int rth_add_mesh(rth_scene*, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt, const rt_material*);
 /* Scene::applySettings (mesh trees) + BVH_Node::buildBVH (top level) + flatten. */
 int rth_build(rth_scene*, int top_depth, int mesh_depth);
-/* ... with Settings::tree_mode for the mesh trees (0 = the reference's builder, 1 = binned SAH with free topology: no parity) */
+/* ... with Settings::tree_mode for the mesh trees (0 = the reference's builder; 1 = binned SAH on the host, 2 = linear BVH built on the GPU
+ * (lbvh.hip; needs a GPU, RT_ERR_DEVICE without one, RT_ERR_LIMIT if the tree comes out deeper than RT_MAX_TREE_DEPTH): free topology,
+ * no parity) */
 int rth_build_mode(rth_scene*, int top_depth, int mesh_depth, int tree_mode);
 const rt_scene_desc* rth_scene_desc(rth_scene*);
 int rth_ray_trace_from_camera(rt_ctx*, rth_scene*, const rt_camera*, const rt_render_params*, const char* ppm_path, double* seconds);

@@ -299,7 +299,7 @@ class HostScene:
             raise RtError(f"rth_add_mesh failed ({rc})")
 
     def build(self, top_depth=3, mesh_depth=12, tree_mode=0):
-        """tree_mode 0: the reference's tree builder (parity); 1: binned SAH, free topology (no parity)."""
+        """tree_mode 0: the reference's tree builder (parity); 1: binned SAH on the host, 2: linear BVH built on the GPU (both free topology: no parity)."""
         rc = self.L.rth_build_mode(self.h, top_depth, mesh_depth, tree_mode)
         if rc != RT_OK:
             raise RtError(f"rth_build failed ({rc})")

@@ -8,6 +8,7 @@
  * path would hold in memory.
  */
 #include "rthost.h"
+#include "../lbvh.h"
 
 #include <algorithm>
 #include <chrono>
@@ -511,6 +512,21 @@ void buildBVH(const std::vector<Vec3>& positions, const std::vector<uint32_t>& t
             box.max[k] = p[k] > box.max[k] ? p[k] : box.max[k];
         }
     out.rootBox = box;
+    if (tree_mode == 2 && nt >= 2) {
+        /* Mode 2 of Settings::tree_mode, NOT the reference's tree either: a linear BVH built on the GPU (lbvh.hip; SURVEY
+         * 8(f).2, "BVH construction on GPU"), one triangle per leaf, same flattened layout. A non-parity mode, off by default. */
+        static_assert(sizeof(Vec3) == 12, "positions are handed to the device as packed floats");
+        out.nodes.resize(nt - 1); out.leaves.resize(nt); out.items.resize(nt);
+        char err[256];
+        double dev_s = 0.0;
+        const auto T0 = std::chrono::steady_clock::now();
+        const int rc = rtgpu_lbvh_build(reinterpret_cast<const float*>(positions.data()), (int64_t)positions.size(), triangles.data(), (int64_t)nt, out.nodes.data(),
+                                        out.leaves.data(), out.items.data(), &out.root, &out.depth, &dev_s, err, sizeof err);
+        if (rc != RT_OK) throw BuildError{rc, err};
+        if (getenv("RTH_TIMING")) fprintf(stderr, "[rthost] GPU-built tree of %zu triangles: %.3f s on the device, %.3f s with copies; depth %d\n", nt, dev_s,
+                                          std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count(), out.depth);
+        return;
+    }
     out.items.reserve(nt); out.nodes.reserve(nt); out.leaves.reserve(nt + 1);
     const auto T0 = std::chrono::steady_clock::now();
     int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
@@ -1158,6 +1174,7 @@ struct rth_scene { rth::Scene scene; rth::Settings settings; };
 template <typename F>
 static int guarded(F body) {
     try { return body(); }
+    catch (const rth::BuildError& e) { fprintf(stderr, "[rthost] %s\n", e.message.c_str()); return e.code; }
     catch (const std::bad_alloc&) { return RT_ERR_NOMEM; }
     catch (...) { return RT_ERR_ARG; }
 }
@@ -1234,7 +1251,7 @@ int rth_add_mesh(rth_scene* s, const float* verts, int64_t nv, const uint32_t* t
 }
 int rth_build(rth_scene* s, int top_depth, int mesh_depth) { return rth_build_mode(s, top_depth, mesh_depth, 0); }
 int rth_build_mode(rth_scene* s, int top_depth, int mesh_depth, int tree_mode) {
-    if (!s || top_depth < 0 || mesh_depth < 0 || tree_mode < 0 || tree_mode > 1) return RT_ERR_ARG;
+    if (!s || top_depth < 0 || mesh_depth < 0 || tree_mode < 0 || tree_mode > 2) return RT_ERR_ARG;
     if (top_depth > RT_MAX_TOP_DEPTH || mesh_depth > RT_MAX_TREE_DEPTH) return RT_ERR_LIMIT;
     return guarded([&] {
         s->settings.tree_subdivide = (unsigned)mesh_depth;
