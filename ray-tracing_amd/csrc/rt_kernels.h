@@ -486,6 +486,47 @@ RT_DEV void accumulate(long long* acc, uint32_t* nonfinite, Counters* ctr, uint3
     }
 }
 
+/* accumulate() for a whole wave whose neighbouring lanes mostly add to the same pixel (k_shade: the diffuse records of a
+ * batch of primaries come sample after sample, pixel after pixel, so a wave holds a few runs of up to 64 equal slots):
+ * the ordinary contributions (finite, below 64) are summed over each run of lanes with equal slot -- integer sums, so the
+ * accumulators end with the same bits -- and the run's first lane adds the total: three atomics per run instead of per
+ * lane, and the L2 no longer serialises dozens of adds to one address. Contributions that take accumulate()'s careful
+ * paths (not finite, or large) still go one by one. Every lane of the wave must call this (active = false: nothing to add). */
+RT_DEV void accumulate_runs(long long* acc, uint32_t* nonfinite, Counters* ctr, uint32_t slot, F3 c, bool active) {
+    const float v[3] = {c.x, c.y, c.z};
+    long long q[3] = {0, 0, 0};
+    if (active) {
+        F3 careful = f3s(0.f);
+        bool any = false;
+        float* cv[3] = {&careful.x, &careful.y, &careful.z};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (fabsf(v[k]) < 64.0f) q[k] = __double2ll_rn((double)v[k] * RT_FIX_SCALE);
+            else { *cv[k] = v[k]; any = true; }
+        }
+        if (any) accumulate(acc, nonfinite, ctr, slot, careful);      /* (its other channels are zeros: nothing added) */
+    } else slot = 0xFFFFFFFFu;
+    const int lane = __lane_id();
+    const uint32_t prev = __shfl_up(slot, 1);
+    const bool head = lane == 0 || prev != slot;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long later = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
+    const int next_head = later ? __builtin_ctzll(later) : 64;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const long long other = __shfl_down(q[k], off);
+            if (lane + off < next_head) q[k] += other;
+        }
+    }
+    if (head && active) {
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (q[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(acc + 3 * (size_t)slot + k), (unsigned long long)q[k]);
+    }
+}
+
 /* Block-aggregated append to the two queues of k_closest at once: every thread of the block calls this (no early
  * exits before it) with its own request counts. All waves of all blocks used to hit the same two counters with
  * returning atomics (plus two for the ray statistics): on scenes with cheap rays that contention, not the
@@ -617,6 +658,8 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
     uint32_t slot = 0, pixel = 0, sample = 0, flags = 0;
     uint64_t code = 0;
     int remaining = 0;
+    F3 sky_add = f3s(0.f);        /* a miss adds the sky (below, by runs of lanes on one pixel) */
+    bool missed = false;
 
     if (active) {
         const float4* p = reinterpret_cast<const float4*>(in + i);
@@ -636,7 +679,8 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
             float t = (float)(0.5 * ((double)r.d.y + 1.0));
             float omt = (float)(1.0 - (double)t);
             F3 sky = add(mul(omt, f3s(1.0f)), mul(t, f3(0.5f, 0.7f, 1.0f)));
-            accumulate(acc, nonfinite, ctr, slot, comp(thr, sky));
+            sky_add = comp(thr, sky);
+            missed = true;
         } else {
             DMat m = sc.mats[h.mat];
             uint32_t matword = (uint32_t)h.mat;
@@ -744,6 +788,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
         }
     }
 
+    if (__ballot(missed) != 0ull) accumulate_runs(acc, nonfinite, ctr, slot, sky_add, missed);
     {   /* culled hits: one atomic per wave that has any */
         const unsigned long long cm = __ballot(culled);
         if (cm && __lane_id() == 0) atomicAdd(&ctr->culled, (unsigned long long)__popcll(cm));
@@ -1521,7 +1566,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
 __global__ void __launch_bounds__(256) k_shade(DScene sc, const DiffuseRec* __restrict__ drec, const uint32_t* __restrict__ dtex, uint32_t n_rec, int S,
                                                const uint32_t* __restrict__ cnt, long long* acc, uint32_t* nonfinite, Counters* ctr) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rec) return;
+    const bool active = i < n_rec;
+    if (!active) i = n_rec - 1;                      /* (a valid record to read; nothing of it is added) */
     const float4* q = reinterpret_cast<const float4*>(drec + i);
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     F3 P = f3(q0.x, q0.y, q0.z), N = f3(q0.w, q1.x, q1.y), V = f3(q1.z, q1.w, q2.x), thr = f3(q2.y, q2.z, q2.w);
@@ -1553,7 +1599,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, const DiffuseRec* __re
     }
     float f = (float)(1. - (double)(avg / (float)sc.n_lights));
     color = mul(f, color);
-    accumulate(acc, nonfinite, ctr, slot, comp(thr, color));
+    accumulate_runs(acc, nonfinite, ctr, slot, comp(thr, color), active);
 }
 
 __global__ void __launch_bounds__(256) k_resolve(const long long* acc, const uint32_t* nonfinite, uint32_t n_pix, int spp, float* rgb) {
