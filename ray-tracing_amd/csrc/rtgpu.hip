@@ -74,6 +74,7 @@ struct rt_ctx {
                                    * 1112 / 1244 / 1280 Mrays/s (gorilla 75.6 / 65.8 / 61.8 ms per frame with 1 / 4 / 16 Mi) */
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
+    bool separate_raygen = false;   /* test knob RT_SEPARATE_RAYGEN=1: k_raygen writes the primaries out and k_closest loads them (the two ways must agree bit for bit) */
     int front_state = -1;       /* the front pass of the shadow rays (k_shadow_front): -1 = to be probed on this scene, 0 = off, 1 = on */
     Counters* h_ctr = nullptr;  /* pinned */
     rt_stats stats{};
@@ -306,9 +307,14 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         /* 1. top up with fresh primaries */
         uint32_t room = top < B ? (uint32_t)(B - top) : 0u;
         uint32_t n_new = (uint32_t)std::min<unsigned long long>(src.total - done, room);
+        const bool fuse_raygen = src.from_tiles && !c->separate_raygen;     /* the fresh primaries of queued tiles are made inside k_closest */
+        FreshD fresh{};
         if (n_new) {
             dim3 g((n_new + 255) / 256), b(256);
-            if (src.from_tiles)
+            if (fuse_raygen) {
+                fresh.cam = c->cam; fresh.fr = c->fr; fresh.tiles = static_cast<const TileD*>(w.tilebuf); fresh.n_tiles = (int)c->tiles.size();
+                fresh.first = done;
+            } else if (src.from_tiles)
                 hipLaunchKernelGGL(k_raygen, g, b, 0, c->stream, c->cam, c->fr, static_cast<const TileD*>(w.tilebuf), (int)c->tiles.size(),
                                    done, n_new, stack + top);
             else
@@ -331,10 +337,17 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         if (!getenv("RT_CBLOCK")) cblock = (2ull * n_new >= nb) ? cblock_light : 64u;
         auto launch_closest = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((nb + cblock - 1) / cblock), dim3(cblock), lds_bytes_closest(c, cblock) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, c->sc, stack + base, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
-                               w.child, 2 * B, w.drec, w.dcode, w.dtex, B, d_ctr, acc, nonfinite, prim);
+                               w.child, 2 * B, w.drec, w.dcode, w.dtex, B, d_ctr, acc, nonfinite, prim, fresh);
         };
-        if (c->sc.has_sub && c->sc.quant_ok) { if (cblock == 64u) launch_closest(k_closest<true, 64>); else launch_closest(k_closest<true, RT_CBLOCK>); }
-        else { if (cblock == 64u) launch_closest(k_closest<false, 64>); else launch_closest(k_closest<false, RT_CBLOCK>); }
+        fresh.n_old = nb - n_new;
+        const bool sub = c->sc.has_sub && c->sc.quant_ok;
+        if (fuse_raygen && n_new) {
+            if (sub) { if (cblock == 64u) launch_closest(k_closest<true, 64, true>); else launch_closest(k_closest<true, RT_CBLOCK, true>); }
+            else { if (cblock == 64u) launch_closest(k_closest<false, 64, true>); else launch_closest(k_closest<false, RT_CBLOCK, true>); }
+        } else {
+            if (sub) { if (cblock == 64u) launch_closest(k_closest<true, 64, false>); else launch_closest(k_closest<true, RT_CBLOCK, false>); }
+            else { if (cblock == 64u) launch_closest(k_closest<false, 64, false>); else launch_closest(k_closest<false, RT_CBLOCK, false>); }
+        }
         if (e1) HIP_TRY(c, hipEventRecord(e1->b, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_ctr, w.ctr, 16, hipMemcpyDeviceToHost, c->stream));
         if (c->front_state < 0 && front_rays) HIP_TRY(c, hipMemcpyAsync(&c->h_ctr->deferred_sum, &d_ctr->deferred_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1118,6 +1131,7 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->persistent_blocks = prop.multiProcessorCount * 16;    /* measured on C5: 16 one-wave blocks per CU (4 per SIMD) beat 12/14/18/20; more rays in flight thrash L1/L2 */
+        c->separate_raygen = getenv("RT_SEPARATE_RAYGEN") != nullptr;
         const char* pb = getenv("RT_PERSISTENT_BLOCKS");
         if (pb && atoi(pb) > 0) c->persistent_blocks = atoi(pb);
     }
