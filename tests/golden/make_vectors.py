@@ -31,6 +31,7 @@ CONFIGS = {
     "C4_mesh_gorilla_1080p": dict(scene="mesh_gorilla", mesh_depth=12, w=1920, h=1080, crop=64, zoom=3.0, max_depth=50),
     "C4_mesh_cow_1080p": dict(scene="mesh_cow", mesh_depth=12, w=1920, h=1080, crop=64, zoom=3.0, max_depth=50),
     "F1_reflexion_chamber": dict(scene="reflexion_chamber", mesh_depth=12, w=480, h=480, crop=48, zoom=3.0, max_depth=50),
+    "F1_cornell_box": dict(scene="cornell_box", mesh_depth=12, w=480, h=480, crop=48, zoom=3.0, max_depth=50),
     "C5_soup_200k_4k": dict(scene="soup:200000", mesh_depth=18, w=3840, h=2160, crop=48, zoom=3.0, max_depth=5),
     # the benched scene itself; its oracle takes a while to build, so only the GPU test loads this one
     "C5_soup_10M_4k": dict(scene="soup:10000000", mesh_depth=24, w=3840, h=2160, crop=32, zoom=3.0, max_depth=5),
