@@ -69,9 +69,11 @@ struct rt_ctx {
     unsigned long long queued_samples = 0;
 
     DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays, dtex, ovf;
-    uint32_t batch = 8u << 20;    /* path states per wavefront iteration (RT_BATCH). One batch of diffuse hits is one launch of the persistent shadow kernel, and
-                                   * every launch ends in a tail of a few ms in which the longest rays finish alone: measured on C5 at 1 / 4 / 8 Mi states
-                                   * 1112 / 1244 / 1280 Mrays/s (gorilla 75.6 / 65.8 / 61.8 ms per frame with 1 / 4 / 16 Mi) */
+    uint32_t batch = 32u << 20;   /* path states per wavefront iteration at most (RT_BATCH). One batch of diffuse hits is one launch of the persistent shadow kernel, and
+                                   * every launch ends in a tail of a few ms in which the longest rays finish alone: measured on C5 at 1 / 4 / 8 / 16 / 32 Mi states
+                                   * 1112 / 1244 / 1334 / 1340 / 1358 Mrays/s (gorilla 75.6 / 65.8 / 61.8 ms per frame with 1 / 4 / 16 Mi). What a batch really
+                                   * gets is bounded by the call's own primaries and by mem_budget (bufs_from_ctx). */
+    unsigned long long mem_budget = 96ull << 30;    /* bytes the buffers of the wavefront loop may take together (RT_MEM_BUDGET_GB; HBM is 288 GB) */
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
     bool separate_raygen = false;   /* test knob RT_SEPARATE_RAYGEN=1: k_raygen writes the primaries out and k_closest loads them (the two ways must agree bit for bit) */
@@ -242,9 +244,15 @@ int wide_ovf_cap(const rt_ctx* c, int* lds_cap_out) {
 /* the library's own buffers, grown to what this run can need */
 int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
     /* no more states per iteration than the call has primaries (a small frame must not size the buffers of a big one) */
-    const uint32_t B = (uint32_t)std::min<unsigned long long>(c->batch, (std::max<unsigned long long>(src.total, 4096ull) + 1023ull) & ~1023ull);
     const int L = c->n_lights;
     const int S = c->fr.shadow_mode == 1 ? 1 : c->fr.light_samples;
+    /* a batch costs, per state: its place on the stack at every depth, two children, a diffuse record with code, texel and
+     * counters, and the shadow rays of its hit (32 bytes each, unless the scene has no meshes: no ray buffer then) */
+    const bool no_ray_buffer = (c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW")) || L == 0;
+    const unsigned long long per_state = (unsigned long long)sizeof(PathState) * (unsigned long long)(src.max_depth + 3 + 2) + sizeof(DiffuseRec) + 12ull +
+                                         4ull * (unsigned long long)std::max(L, 1) + (no_ray_buffer ? 0ull : 32ull * (unsigned long long)std::max(L, 1) * (unsigned long long)S);
+    const unsigned long long affordable = std::max<unsigned long long>(1ull << 20, (c->mem_budget / per_state) & ~1023ull);
+    const uint32_t B = (uint32_t)std::min<unsigned long long>(std::min<unsigned long long>(c->batch, affordable), (std::max<unsigned long long>(src.total, 4096ull) + 1023ull) & ~1023ull);
     size_t need_stack = (size_t)B * (size_t)(src.max_depth + 3);
     int rc;
     if ((rc = ensure(c, c->stack, need_stack * sizeof(PathState)))) return rc;
@@ -256,7 +264,7 @@ int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
     if ((rc = ensure(c, c->ctr, sizeof(Counters)))) return rc;
     if (src.from_tiles && (rc = ensure(c, c->tilebuf, std::max<size_t>(c->tiles.size(), 1) * sizeof(TileD)))) return rc;
     const unsigned long long per_rec = (unsigned long long)std::max(L, 1) * S;
-    unsigned long long ray_cap = 320ull << 20;                  /* rays per k_shadow launch (10 GiB of 32-byte rays; HBM is 288 GB): a batch of 8 Mi hits x 35 samples is one launch */
+    unsigned long long ray_cap = 1280ull << 20;                 /* rays per k_shadow launch at most (40 GiB of 32-byte rays): a batch of 32 Mi hits x 35 samples is one launch */
     if (const char* e = getenv("RT_SHADOW_RAYS")) ray_cap = std::max<unsigned long long>(1ull << 16, strtoull(e, nullptr, 10));
     const unsigned long long chunk = std::max<unsigned long long>(1ull, std::min<unsigned long long>(B, ray_cap / per_rec));
     const bool direct = c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW");
@@ -1125,6 +1133,7 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
     }
     const char* b = getenv("RT_BATCH");
     if (b && atoi(b) >= 1024) c->batch = (uint32_t)atoi(b);
+    if (const char* e = getenv("RT_MEM_BUDGET_GB")) { if (atof(e) >= 1.0) c->mem_budget = (unsigned long long)(atof(e) * 1073741824.0); }
     c->debug = getenv("RT_DEBUG") != nullptr;
     c->count_steps = getenv("RT_COUNT") != nullptr;
     {
