@@ -215,9 +215,13 @@ extern "C" int rtgpu_lbvh_build(const float* positions, int64_t n_verts, const u
     size_t tmp_bytes = 0;
     LBVH_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), (size_t)n, 0, 62));
     LBVH_TRY(d_tmp.alloc(tmp_bytes));
-    hipEvent_t e0, e1;
-    LBVH_TRY(hipEventCreate(&e0));
-    LBVH_TRY(hipEventCreate(&e1));
+    struct Events {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    LBVH_TRY(hipEventCreate(&ev.a));
+    LBVH_TRY(hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     LBVH_TRY(hipEventRecord(e0, 0));
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     hipLaunchKernelGGL(k_centroid_bounds, dim3(std::min<uint32_t>(blocks, 4096u)), dim3(256), 0, 0, d_pos.as<float>(), d_tri.as<uint32_t>(), (uint32_t)n, d_mm.as<uint32_t>());
@@ -231,8 +235,6 @@ extern "C" int rtgpu_lbvh_build(const float* positions, int64_t n_verts, const u
     LBVH_TRY(hipGetLastError());
     float ms = 0.f;
     LBVH_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (device_seconds) *device_seconds = ms * 1e-3;
     LBVH_TRY(hipMemcpy(nodes_out, d_nodes.p, (size_t)(n - 1) * sizeof(rt_bvh_node), hipMemcpyDeviceToHost));
     LBVH_TRY(hipMemcpy(leaves_out, d_leaves.p, (size_t)n * sizeof(rt_bvh_leaf), hipMemcpyDeviceToHost));
