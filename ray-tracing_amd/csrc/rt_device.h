@@ -102,6 +102,7 @@ struct DScene {
     int32_t cstack_cap;         /* ... of the closest-hit walks (stack_cap + the sub-tree of a fat leaf) */
     int32_t wstack_cap;         /* per-lane stack entries the 4-wide shadow walk can need (three pending links per level) */
     int32_t quant_ok;           /* all mesh boxes are finite and nested: the 32-byte shadow nodes may be used */
+    int32_t wide_closest;       /* closest hits walk the 4-wide quantised tree too (mesh_closest_wide) */
     int32_t n_top_items;        /* entries of the top-level item lists */
     int32_t has_sub;            /* some leaves carry a sub-tree (rtgpu.hip, LeafSplitter) */
     /* the top-level tables once more, packed into one blob that k_shadow copies into LDS when it is small:

@@ -230,6 +230,149 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
     }
 }
 
+/* Of two leaves of one mesh that the reference both reaches, does it reach A first? Their order is decided at their
+ * lowest common ancestor: BVH_Node::intersect lists the leaves below the nearer child first (tL <= tR: left,
+ * AccelerationStruct.cpp:270-279). The path words (rtgpu.hip: bit 63 = the root's decision, 1 = right; depth in the low
+ * six bits) locate that node; both of its children are hit (each holds a reached leaf, and the boxes are nested), so both
+ * entry times are the ones the reference compares. Only runs for two hits with the very same t in different leaves. */
+RT_DEV bool leaf_comes_first(const DScene& sc, const DMesh& m, const Ray& r, unsigned long long wa, unsigned long long wb) {
+    const unsigned long long x = (wa ^ wb) & ~63ull;
+    if (x == 0ull) return false;
+    const int k = __builtin_clzll(x);                   /* decisions the two paths share = depth of the common ancestor */
+    int node = m.root;
+    for (int i = 0; i < k && node >= 0; i++) {
+        const float4 d = sc.mnodes[4 * (size_t)node + 3];
+        node = ((wa >> (63 - i)) & 1ull) ? __float_as_int(d.y) : __float_as_int(d.x);
+    }
+    if (node < 0) return false;
+    const float4* nd = sc.mnodes + 4 * (size_t)node;
+    const float4 a = nd[0], b = nd[1], c = nd[2];
+    float tL, tR;
+    slab(r, a.x, a.y, a.z, a.w, b.x, b.y, tL);
+    slab(r, b.z, b.w, c.x, c.y, c.z, c.w, tR);
+    const bool nearLeft = tL <= tR;                     /* AccelerationStruct.cpp:273 */
+    const bool aLeft = ((wa >> (63 - k)) & 1ull) == 0ull;
+    return aLeft == nearLeft;
+}
+
+/* mesh_closest over the 4-wide quantised tree of the shadow walk (DScene::wide_closest): half the node visits, a quarter
+ * of the node bytes. What the reference returns is the hit with the smallest t among the triangles of the leaves it
+ * reaches, and of equal t the one it meets first. It reaches exactly the leaves whose own box passes its test (see
+ * "quantised shadow nodes" below), so the route to the leaves is free: here the nearest hit child of a wide node goes
+ * first and children beyond the best hit so far are dropped (their boxes hold every hit accepted below them). The
+ * leaf's own box is tested with the reference's arithmetic, the triangles likewise, and a tie in t between two leaves is
+ * settled by leaf_comes_first -- the same hit, bit for bit. */
+template <bool SUB>
+RT_DEV void mesh_closest_wide(const DScene& sc, const DMesh& m, const Ray& r, float bound, int* stk, int stride, int sp0,
+                              bool& found, float& bestT, uint32_t& bestG, float& bw0, float& bw1, float& bw2) {
+    found = false;
+    bestT = FLT_MAX;
+    bestG = 0; bw0 = bw1 = bw2 = 0.f;
+    int link = m.wroot;
+    if (link == LINK_NONE) return;
+    QuantRay qr;
+    quant_setup(qr, r, m);
+    if (link >= 0) {            /* the mesh's whole frame, as in shadow_top_item */
+        bool may;
+        quant_entry(0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, qr, (link & WIDE_UNPRUNED) ? 100.0f : fminf(100.0f, bound * 1.00002f), may);
+        if (!may) return;
+    }
+    uint32_t bestLeaf = 0xFFFFFFFFu, bestP = 0;
+    unsigned long long bestPath = 0ull;
+    int sp = sp0;
+    for (;;) {
+        if (link >= 0) {
+            const float near = fminf(bound, bestT) * 1.00002f;
+            const float lim = (link & WIDE_UNPRUNED) ? 100.0f : fminf(100.0f, near);      /* tMax of AABB::intersect */
+            const uint4* nd = sc.wnodes + 4 * (size_t)(link & WIDE_INDEX);
+            const uint4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+            bool h0, h1, h2, h3;
+            float t0 = quant_entry(a.x, a.y, a.z, qr, lim, h0);
+            float t1 = quant_entry(a.w, b.x, b.y, qr, lim, h1);
+            float t2 = quant_entry(b.z, b.w, c.x, qr, lim, h2);
+            float t3 = quant_entry(c.y, c.z, c.w, qr, lim, h3);
+            const int l0 = (int)d.x, l1 = (int)d.y, l2 = (int)d.z, l3 = (int)d.w;
+            t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
+            float ta = t0; int la = l0, ia = 0;
+            if (t1 < ta) { ta = t1; la = l1; ia = 1; }
+            if (t2 < ta) { ta = t2; la = l2; ia = 2; }
+            if (t3 < ta) { ta = t3; la = l3; ia = 3; }
+            if (h0 || h1 || h2 || h3) {
+                if (!(ta < INFINITY)) { la = h0 ? l0 : h1 ? l1 : h2 ? l2 : l3; ia = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3; }    /* (hit with a NaN or infinite entry time) */
+                if (h0 && ia != 0) stk[lds_index(sp++, stride)] = l0;
+                if (h1 && ia != 1) stk[lds_index(sp++, stride)] = l1;
+                if (h2 && ia != 2) stk[lds_index(sp++, stride)] = l2;
+                if (h3 && ia != 3) stk[lds_index(sp++, stride)] = l3;
+                link = la;
+                continue;
+            }
+        } else {
+            const uint32_t g = leaf_first(link);
+            const float4* lq = sc.tri + RT_TRI_STRIDE * (size_t)g;
+            const float4 b0 = lq[4], b1 = lq[5];
+            float tEnter;
+            if (slab(r, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tEnter)) {     /* the reference's test of the leaf's own box */
+                const unsigned long long path = (unsigned long long)__float_as_uint(b1.z) | ((unsigned long long)__float_as_uint(b1.w) << 32);
+                auto candidate = [&](uint32_t gi, const float4* q, float4 q2, float4 q3) {
+                    float t, w0, w1, w2;
+                    if (tri_test(r, q[0], q[1], q2, q3, t, w0, w1, w2)) {
+                        const uint32_t p = __float_as_uint(q3.w);
+                        bool better = t < bestT;
+                        if (!better && found && t == bestT)      /* Mesh.cpp:114, strict <: of equal t the one the reference meets first */
+                            better = bestLeaf == g ? p < bestP : leaf_comes_first(sc, m, r, path, bestPath);
+                        if (better) {
+                            found = true; bestT = t; bestG = gi; bw0 = w0; bw1 = w1; bw2 = w2;
+                            bestLeaf = g; bestP = p; bestPath = path;
+                        }
+                    }
+                };
+                const float4 gate = SUB ? lq[6] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (__float_as_uint(gate.y) != 0u) {
+                    /* a fat leaf: its sub-tree of runs, walked on the spot (the hits of the whole leaf count as one leaf's) */
+                    const int spl = sp;
+                    int sub = __float_as_int(gate.x);
+                    for (;;) {
+                        if (sub >= 0) {
+                            const uint4* nd = sc.wnodes + 4 * (size_t)(sub & WIDE_INDEX);
+                            const uint4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+                            const float lim = (sub & WIDE_UNPRUNED) ? INFINITY : fminf(bound, bestT) * 1.00002f;     /* (no tMax below the leaf's own box) */
+                            bool h0, h1, h2, h3;
+                            quant_entry(a.x, a.y, a.z, qr, lim, h0);
+                            quant_entry(a.w, b.x, b.y, qr, lim, h1);
+                            quant_entry(b.z, b.w, c.x, qr, lim, h2);
+                            quant_entry(c.y, c.z, c.w, qr, lim, h3);
+                            if (h0) stk[lds_index(sp++, stride)] = (int)d.x;
+                            if (h1) stk[lds_index(sp++, stride)] = (int)d.y;
+                            if (h2) stk[lds_index(sp++, stride)] = (int)d.z;
+                            if (h3) stk[lds_index(sp++, stride)] = (int)d.w;
+                        } else {
+                            uint32_t gi = leaf_first(sub) & ~TRI_SUB;
+                            for (bool last = false; !last; gi++) {
+                                const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)gi;
+                                float4 q2 = q[2];
+                                last = __float_as_uint(q2.w) != 0u;
+                                candidate(gi, q, q2, q[3]);
+                            }
+                        }
+                        if (sp == spl) break;
+                        sub = stk[lds_index(--sp, stride)];
+                    }
+                } else {
+                    uint32_t gi = g;
+                    for (bool last = false; !last; gi++) {
+                        const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)gi;
+                        float4 q2 = q[2];
+                        last = (__float_as_uint(q2.w) & TRI_LEAF_END) != 0u;
+                        candidate(gi, q, q2, q[3]);
+                    }
+                }
+            }
+        }
+        if (sp == sp0) break;
+        link = stk[lds_index(--sp, stride)];
+    }
+}
+
 /* Same candidate set, shadow use: is any triangle hit at t <= bound? (Order does not matter for
  * that answer, so the nearer child goes first to find an occluder early.) With prune=false and
  * bound just below FLT_MAX this is "does RayTraceMesh::intersect return a hit at all". */
@@ -316,7 +459,8 @@ RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
                 } else {
                     DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
                     bool found; float t; uint32_t g; float w0, w1, w2;
-                    mesh_closest<SUB>(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
+                    if (sc.wide_closest) mesh_closest_wide<SUB>(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
+                    else mesh_closest<SUB>(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
                     if (found && t < best.t) {
                         best.exists = 1; best.t = t; best.obj = ord; kind = 2;
                         bestG = g; bw0 = w0; bw1 = w1; bw2 = w2; best.mat = m.material;

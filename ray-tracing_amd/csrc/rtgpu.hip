@@ -1222,6 +1222,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     }
     bool quant_ok = true;
     int max_mesh_depth = 0, max_wide_depth = 0, max_sub_depth = 0, max_wide_sub_depth = 0, max_wide_top_depth = 0;
+    bool wide_paths_ok = true;      /* every leaf's path from its root fits a 64-bit word (see the path words below) */
     for (int mi = 0; mi < d->n_meshes; mi++) {
         const rt_mesh& m = d->meshes[mi];
         max_mesh_depth = std::max(max_mesh_depth, m.depth);
@@ -1385,6 +1386,33 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
         qnodes.resize(2 * (sub_base + subs.size()), make_uint4(0u, 0u, 0u, 0u));
         qunp.resize(2 * (sub_base + subs.size()), 0);
         quant_ok = quantise_mesh(d, m, nodes, empty_link, meshes[mi], qnodes, tri, hbox, qunp, subs, sub_lo, sub_base) && quant_ok;
+        /* Words 22-23 of a leaf's first record: the leaf's path from the root (bit 63 = the root's decision, 0 left / 1 right,
+         * one bit per level; the depth in the low six bits). The closest-hit walk over the 4-wide tree visits leaves in an
+         * order of its own, and of two hits with the same t the reference keeps the one it reaches first (Mesh.cpp:114):
+         * the order of two leaves is decided at their lowest common ancestor (the nearer child's leaves come first,
+         * AccelerationStruct.cpp:270-279), which two path words locate (rt_kernels.h, leaf_comes_first). */
+        if (meshes[mi].root >= 0) {
+            std::vector<std::pair<int32_t, unsigned long long>> todo;      /* (inner node, path so far | depth) */
+            todo.emplace_back(meshes[mi].root, 0ull);
+            while (!todo.empty()) {
+                const auto [node, word] = todo.back();
+                todo.pop_back();
+                const unsigned depth = (unsigned)(word & 63ull);
+                const int32_t child[2] = {nodes[(size_t)node].left, nodes[(size_t)node].right};
+                for (int side = 0; side < 2; side++) {
+                    if (child[side] == empty_link) continue;
+                    if (depth >= 57u) { wide_paths_ok = false; continue; }
+                    const unsigned long long w = ((word & ~63ull) | ((unsigned long long)side << (63u - depth))) | (unsigned long long)(depth + 1u);
+                    if (child[side] >= 0) todo.emplace_back(child[side], w);
+                    else {
+                        float4& q5 = tri[RT_TRI_STRIDE * (size_t)(-2 - (int64_t)child[side]) + 5];
+                        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+                        memcpy(&q5.z, &lo, 4);
+                        memcpy(&q5.w, &hi, 4);
+                    }
+                }
+            }
+        }
         {
             WideFold wf{qnodes, empty_link, meshes[mi].qstep, wnodes, qunp};
             if (meshes[mi].root >= 0) meshes[mi].wroot = wf.build(meshes[mi].root, 0);
@@ -1796,6 +1824,9 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     }
 
     sc.quant_ok = (quant_ok && !getenv("RT_SHADOW_EXACT_NODES")) ? 1 : 0;
+    /* closest hits over the 4-wide quantised tree (rt_kernels.h, mesh_closest_wide): up to three links pending per level */
+    sc.wide_closest = quant_ok && wide_paths_ok && !getenv("RT_SHADOW_EXACT_NODES") && !getenv("RT_NO_WIDE_CLOSEST") ? 1 : 0;
+    if (sc.wide_closest) sc.cstack_cap = std::max(sc.cstack_cap, sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 6);
     {   /* The per-lane stacks of the walks live in LDS (4 bytes x entries x threads of the block; k_shadow's wide stack spills
          * beyond stack_cap). What a launch may ask for is a documented limit, not a launch failure at rt_flush: the one-wave
          * build of k_closest / k_intersect must fit (the 256-thread build is only chosen when it fits, run_wavefront). */
