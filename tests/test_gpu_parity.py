@@ -387,6 +387,55 @@ def test_random_scenes(rt, ctx, seed):
         radiance_check(g, o, f"random scene {seed} mode {shadow_mode}")
 
 
+@pytest.mark.parametrize("mesh_depth", [3, 12])
+def test_equal_t_in_different_leaves(rt, ctx, monkeypatch, mesh_depth):
+    """Two overlapping triangle grids in the plane z = -3 (normals exactly +-z, so every triangle of the mesh gives the very
+    same t for a ray): each ray that hits the mesh hits two or more triangles at one t, mostly in different leaves, and the
+    reference keeps the one whose leaf it reaches first (Mesh.cpp:114 strict <, BVH_Node::intersect's near-child-first
+    order). The closest-hit walk over the 4-wide tree visits leaves in its own order and has to name the same triangle."""
+    n = 24
+    xs = np.arange(n + 1, dtype=np.float32) * 0.25 - 3.0
+    gx, gy = np.meshgrid(xs, xs, indexing="xy")
+    base = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, -3.0, np.float32)], axis=1)
+    shifted = base + np.array([0.125, 0.0625, 0.0], np.float32)
+    verts = np.concatenate([base, shifted]).astype(np.float32)
+    tris = []
+    for off in (0, base.shape[0]):
+        for j in range(n):
+            for i in range(n):
+                a = off + j * (n + 1) + i
+                b, c, d = a + 1, a + n + 1, a + n + 2
+                tris.append([a, b, d] if (i + j) % 2 else [a, d, b])      # both windings: the normal's sign does not change t
+                tris.append([a, d, c])
+    tris = np.array(tris, np.uint32)
+    hs, os_ = rt.HostScene(), O.Scene()
+    for s, M in ((hs, rt), (os_, O)):
+        m = M.Material()
+        m.kd[:] = [0.7, 0.7, 0.7]
+        s.add_light([0.0, 0.0, 4.0], 0.3)
+        s.add_mesh(verts, tris, m)
+        s.build(1, mesh_depth)
+    r = np.random.default_rng(5 + mesh_depth)
+    k = 30000
+    aim = np.stack([r.uniform(-3.2, 3.3, k), r.uniform(-3.2, 3.3, k), np.full(k, -3.0)], axis=1)
+    aim[:2000, :2] = np.round(aim[:2000, :2] * 4.0) / 4.0                    # through grid vertices and along edges
+    aim[2000:4000, 0] = np.round(aim[2000:4000, 0] * 4.0) / 4.0
+    org = np.stack([r.uniform(-6, 6, k), r.uniform(-6, 6, k), r.uniform(-1.0, 5.0, k)], axis=1)
+    dirs = (aim - org).astype(np.float32)
+    org = org.astype(np.float32)
+    oh = os_.intersect(org, dirs)
+    assert oh["exists"].mean() > 0.8
+    ctx.upload_scene(hs)
+    assert_hits_equal(ctx.intersect(org, dirs), oh, "coplanar grids")
+    monkeypatch.setenv("RT_NO_WIDE_CLOSEST", "1")
+    c2 = rt.Context(0)
+    try:
+        c2.upload_scene(hs)
+        assert_hits_equal(c2.intersect(org, dirs), oh, "coplanar grids, binary walk")
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("name", ["refraction", "reflexion"])
 def test_direct_shadow_kernel_equals_the_persistent_one(rt, ctx, monkeypatch, name):
     """Scenes without meshes take k_shadow_direct (one thread per shadow ray, no ray buffer); the persistent kernel gives
