@@ -416,7 +416,7 @@ RT_DEV bool mesh_any(const DScene& sc, const DMesh& m, const Ray& r, float bound
 
 /* BVH_Node::intersectObjects(ray) with stopAtFirst=false (AccelerationStruct.cpp:286-337):
  * every hit child is visited, left first; ties keep the earlier result. */
-template <bool SUB>
+template <bool SUB, bool WIDE>     /* WIDE: meshes are walked over the 4-wide quantised tree (mesh_closest_wide; a kernel of its own, the two walks in one cost the binary one a wave per SIMD) */
 RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
     HitD best;
     best.exists = 0; best.t = FLT_MAX; best.obj = -1; best.tri = 0; best.mat = 0;
@@ -459,7 +459,7 @@ RT_DEV HitD closest_hit(const DScene& sc, const Ray& r, int* stk, int stride) {
                 } else {
                     DMesh m = sc.meshes[ord - sc.n_squares - sc.n_spheres];
                     bool found; float t; uint32_t g; float w0, w1, w2;
-                    if (sc.wide_closest) mesh_closest_wide<SUB>(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
+                    if (WIDE) mesh_closest_wide<SUB>(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
                     else mesh_closest<SUB>(sc, m, r, best.t, stk, stride, sc.top_cap, found, t, g, w0, w1, w2);
                     if (found && t < best.t) {
                         best.exists = 1; best.t = t; best.obj = ord; kind = 2;
@@ -787,8 +787,8 @@ __global__ void __launch_bounds__(256) k_seed(const float* org, const float* dir
  * makes its camera ray itself (k_raygen's arithmetic) instead of loading a 64-byte state that k_raygen would have stored a
  * moment before -- 8 GB less traffic on a 1080p frame at 30 spp. */
 struct FreshD { CameraD cam; FrameD fr; const TileD* tiles; int n_tiles; unsigned long long first; uint32_t n_old; };
-template <bool SUB, int BLOCK, bool FRESH>      /* BLOCK: the largest block it is launched with (64 or RT_CBLOCK); the one-wave build is the better one for heavy rays */
-__global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
+template <bool SUB, int BLOCK, bool FRESH, bool WIDE>      /* BLOCK: the largest block it is launched with (64 or RT_CBLOCK); the one-wave build is the better one for heavy rays */
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_closest(DScene sc, const PathState* __restrict__ in, uint32_t n, PathState* child,
                                                       uint32_t child_cap, DiffuseRec* drec, unsigned long long* dcode, uint32_t* dtex,
                                                       uint32_t diffuse_cap, Counters* ctr, long long* acc, uint32_t* nonfinite, uint32_t* prim, FreshD fresh) {
     extern __shared__ __align__(16) int s_stack[];
@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest(DScene sc, const PathState* _
         }
 
         Ray r = make_ray(o, d);
-        HitD h = closest_hit<SUB>(sc, r, stk, stride);
+        HitD h = closest_hit<SUB, WIDE>(sc, r, stk, stride);
         if ((flags & 1u) && prim) {
             prim[2 * (size_t)slot] = h.exists ? (uint32_t)h.obj : 0xFFFFFFFFu;
             prim[2 * (size_t)slot + 1] = h.exists ? (uint32_t)h.tri : 0xFFFFFFFFu;
@@ -1774,13 +1774,13 @@ __global__ void __launch_bounds__(256) k_resolve(const long long* acc, const uin
 
 /* Scene::computeIntersection on explicit rays (rt_intersect). */
 struct HitOut { int32_t exists, obj, tri; float t; float pos[3]; float nrm[3]; float u, v; };
-template <bool SUB>
+template <bool SUB, bool WIDE>
 __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene sc, const float* org, const float* dir, uint32_t n, HitOut* out) {
     extern __shared__ __align__(16) int s_stack[];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r = make_ray(f3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), f3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
-    HitD h = closest_hit<SUB>(sc, r, s_stack + threadIdx.x, blockDim.x);
+    HitD h = closest_hit<SUB, WIDE>(sc, r, s_stack + threadIdx.x, blockDim.x);
     HitOut o;
     o.exists = h.exists; o.obj = h.exists ? h.obj : -1; o.tri = h.exists ? h.tri : 0; o.t = h.exists ? h.t : FLT_MAX;
     o.pos[0] = h.pos.x; o.pos[1] = h.pos.y; o.pos[2] = h.pos.z;

@@ -29,6 +29,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 #include <utility>
 
@@ -76,6 +77,8 @@ struct rt_ctx {
     unsigned long long mem_budget = 96ull << 30;    /* bytes the buffers of the wavefront loop may take together (RT_MEM_BUDGET_GB; HBM is 288 GB) */
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
+    int wide_mode = 2;              /* closest hits over the 4-wide quantised tree: 0 never, 1 always, 2 for batches of bounced rays and rt_intersect (RT_WIDE_CLOSEST=0|1 overrides; see run_wavefront) */
+    int cstack_wide = 0;            /* per-lane stack entries of that walk (three pending links per level); DScene::cstack_cap is what the binary walk needs */
     bool separate_raygen = false;   /* test knob RT_SEPARATE_RAYGEN=1: k_raygen writes the primaries out and k_closest loads them (the two ways must agree bit for bit) */
     int front_state = -1;       /* the front pass of the shadow rays (k_shadow_front): -1 = to be probed on this scene, 0 = off, 1 = on */
     Counters* h_ctr = nullptr;  /* pinned */
@@ -195,7 +198,7 @@ bool m4_inverse(const double* m, double* out) {
 
 size_t lds_bytes(const rt_ctx* c, int block) { return (size_t)c->sc.stack_cap * block * sizeof(int); }
 /* the closest-hit walks also keep the links of a fat leaf's sub-tree on the lane's stack */
-size_t lds_bytes_closest(const rt_ctx* c, int block) { return (size_t)c->sc.cstack_cap * block * sizeof(int); }
+size_t lds_bytes_closest(const rt_ctx* c, int block, bool wide = false) { return (size_t)(wide ? c->cstack_wide : c->sc.cstack_cap) * block * sizeof(int); }
 
 EventPair* next_event(rt_ctx* c, int kind) {
     if (c->ev_used == c->ev_pool.size()) {
@@ -343,19 +346,28 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         }
         /* (a batch of bounced rays is the heavy, divergent kind: default scene 147 ms with one wave per block, 169 with four) */
         if (!getenv("RT_CBLOCK")) cblock = (2ull * n_new >= nb) ? cblock_light : 64u;
+        /* Which mesh walk: the 4-wide quantised tree halves the node fetches but spends more instructions per box, and needs a
+         * deeper stack. Bounced rays are incoherent and wait for their loads: it wins there (k_closest -11 % on the default
+         * scene, -15 % in the mirror chamber). The fresh primaries of a 16-spp frame come sixteen to a pixel, their lanes read
+         * the same lines, and the binary walk over the reference's nodes is the faster one (C5, 32 Mi primaries: 37 ms against
+         * 53). Both return the same hit, bit for bit. */
+        DScene scl = c->sc;
+        scl.wide_closest = (c->sc.wide_closest && (c->wide_mode == 1 || (c->wide_mode == 2 && 2ull * n_new < nb))) ? 1 : 0;
+        const bool wide = scl.wide_closest != 0;
+        if (wide && cblock > 64u && lds_bytes_closest(c, cblock, true) + 64 > c->lds_max) cblock = 64u;
         auto launch_closest = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((nb + cblock - 1) / cblock), dim3(cblock), lds_bytes_closest(c, cblock) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, c->sc, stack + base, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
+            hipLaunchKernelGGL(kern, dim3((nb + cblock - 1) / cblock), dim3(cblock), lds_bytes_closest(c, cblock, wide) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, scl, stack + base, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
                                w.child, 2 * B, w.drec, w.dcode, w.dtex, B, d_ctr, acc, nonfinite, prim, fresh);
         };
         fresh.n_old = nb - n_new;
         const bool sub = c->sc.has_sub && c->sc.quant_ok;
-        if (fuse_raygen && n_new) {
-            if (sub) { if (cblock == 64u) launch_closest(k_closest<true, 64, true>); else launch_closest(k_closest<true, RT_CBLOCK, true>); }
-            else { if (cblock == 64u) launch_closest(k_closest<false, 64, true>); else launch_closest(k_closest<false, RT_CBLOCK, true>); }
-        } else {
-            if (sub) { if (cblock == 64u) launch_closest(k_closest<true, 64, false>); else launch_closest(k_closest<true, RT_CBLOCK, false>); }
-            else { if (cblock == 64u) launch_closest(k_closest<false, 64, false>); else launch_closest(k_closest<false, RT_CBLOCK, false>); }
-        }
+        auto pick_closest = [&](auto fresh_c, auto wide_c) {
+            constexpr bool F = decltype(fresh_c)::value, W = decltype(wide_c)::value;
+            if (sub) { if (cblock == 64u) launch_closest(k_closest<true, 64, F, W>); else launch_closest(k_closest<true, RT_CBLOCK, F, W>); }
+            else { if (cblock == 64u) launch_closest(k_closest<false, 64, F, W>); else launch_closest(k_closest<false, RT_CBLOCK, F, W>); }
+        };
+        if (fuse_raygen && n_new) { if (wide) pick_closest(std::true_type{}, std::true_type{}); else pick_closest(std::true_type{}, std::false_type{}); }
+        else { if (wide) pick_closest(std::false_type{}, std::true_type{}); else pick_closest(std::false_type{}, std::false_type{}); }
         if (e1) HIP_TRY(c, hipEventRecord(e1->b, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_ctr, w.ctr, 16, hipMemcpyDeviceToHost, c->stream));
         if (c->front_state < 0 && front_rays) HIP_TRY(c, hipMemcpyAsync(&c->h_ctr->deferred_sum, &d_ctr->deferred_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1825,14 +1837,17 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
 
     sc.quant_ok = (quant_ok && !getenv("RT_SHADOW_EXACT_NODES")) ? 1 : 0;
     /* closest hits over the 4-wide quantised tree (rt_kernels.h, mesh_closest_wide): up to three links pending per level */
-    sc.wide_closest = quant_ok && wide_paths_ok && !getenv("RT_SHADOW_EXACT_NODES") && !getenv("RT_NO_WIDE_CLOSEST") ? 1 : 0;
-    if (sc.wide_closest) sc.cstack_cap = std::max(sc.cstack_cap, sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 6);
+    c->wide_mode = 2;
+    if (const char* e = getenv("RT_WIDE_CLOSEST")) c->wide_mode = atoi(e) ? 1 : 0;       /* test knob: 1 = every launch, 0 = never */
+    sc.wide_closest = quant_ok && wide_paths_ok && !getenv("RT_SHADOW_EXACT_NODES") && c->wide_mode != 0 ? 1 : 0;
+    c->cstack_wide = std::max(sc.cstack_cap, sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 6);
     {   /* The per-lane stacks of the walks live in LDS (4 bytes x entries x threads of the block; k_shadow's wide stack spills
          * beyond stack_cap). What a launch may ask for is a documented limit, not a launch failure at rt_flush: the one-wave
          * build of k_closest / k_intersect must fit (the 256-thread build is only chosen when it fits, run_wavefront). */
         hipDeviceProp_t prop;
         size_t lds_max = 65536;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.sharedMemPerBlock > 0) lds_max = prop.sharedMemPerBlock;
+        if ((size_t)c->cstack_wide * RT_BLOCK * sizeof(int) + 4096 > lds_max) sc.wide_closest = 0;      /* (the binary walk needs less) */
         const size_t need = (size_t)std::max(sc.cstack_cap, sc.stack_cap) * RT_BLOCK * sizeof(int) + 4096;
         if (need > lds_max) {
             free_scene(c);
@@ -2154,10 +2169,11 @@ int rt_intersect(rt_ctx* c, const float* org, const float* dir, int64_t n, rt_hi
         return rc;
     }
     auto launch_intersect = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(((uint32_t)n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds_bytes_closest(c, RT_BLOCK), c->stream, c->sc,
+        hipLaunchKernelGGL(kern, dim3(((uint32_t)n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds_bytes_closest(c, RT_BLOCK, c->sc.wide_closest != 0), c->stream, c->sc,
                            static_cast<const float*>(a.p), static_cast<const float*>(b.p), (uint32_t)n, static_cast<HitOut*>(o.p));
     };
-    if (c->sc.has_sub && c->sc.quant_ok) launch_intersect(k_intersect<true>); else launch_intersect(k_intersect<false>);
+    if (c->sc.wide_closest) { if (c->sc.has_sub && c->sc.quant_ok) launch_intersect(k_intersect<true, true>); else launch_intersect(k_intersect<false, true>); }
+    else { if (c->sc.has_sub && c->sc.quant_ok) launch_intersect(k_intersect<true, false>); else launch_intersect(k_intersect<false, false>); }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, o.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost);
     release(a); release(b); release(o);

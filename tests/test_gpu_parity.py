@@ -234,7 +234,7 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
                         ("RT_TOP_GLOBAL", "1"), ("RT_FRONT", "1"), ("RT_FRONT", "0"),       # ... with and without the front pass
                         ("RT_NO_TOP_SPLIT", "1"),                                        # ... top-level leaves scanned object by object (no sub-trees over their objects)
                         ("RT_SEPARATE_RAYGEN", "1"),                                     # ... primaries written out by k_raygen instead of made inside k_closest
-                        ("RT_NO_WIDE_CLOSEST", "1"),                                     # ... closest hits over the reference's binary tree instead of the 4-wide quantised one
+                        ("RT_WIDE_CLOSEST", "0"), ("RT_WIDE_CLOSEST", "1"),                # ... closest hits over the reference's binary tree only / over the 4-wide quantised one in every launch (default: bounced batches)
                         ("RT_NO_CULL", "1")):                                            # ... every hit shaded and every path followed, however little it carries
         monkeypatch.setenv(knob, value)
         c5 = rt.Context(0)
@@ -427,7 +427,7 @@ def test_equal_t_in_different_leaves(rt, ctx, monkeypatch, mesh_depth):
     assert oh["exists"].mean() > 0.8
     ctx.upload_scene(hs)
     assert_hits_equal(ctx.intersect(org, dirs), oh, "coplanar grids")
-    monkeypatch.setenv("RT_NO_WIDE_CLOSEST", "1")
+    monkeypatch.setenv("RT_WIDE_CLOSEST", "0")
     c2 = rt.Context(0)
     try:
         c2.upload_scene(hs)
