@@ -35,6 +35,20 @@ __global__ void __launch_bounds__(256) k_rate(float* out, int iters, float a, fl
                 if (KIND == 17) asm volatile("v_min3_f32 %0, %0, %1, 0" : "+v"(x[i]) : "v"(a));
                 if (KIND == 18) asm volatile("v_cmp_le_f32 s[10:11], %0, %1" : : "v"(x[i]), "v"(a) : "s10", "s11");
                 if (KIND == 19) asm volatile("v_cndmask_b32 %0, %0, %1, s[10:11]" : "+v"(x[i]) : "v"(a));
+                if (KIND == 20) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 21) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 22) asm volatile("v_bfe_u32 %0, %0, 16, 16" : "+v"(x[i]));
+                if (KIND == 23) asm volatile("v_lshrrev_b32 %0, 16, %0" : "+v"(x[i]));
+                if (KIND == 24) asm volatile("v_lshl_or_b32 %0, %0, 7, %1" : "+v"(x[i]) : "v"(a));
+                if (KIND == 25) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+                if (KIND == 26) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 27) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+                if (KIND == 28) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+                if (KIND == 29) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 30) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 31) asm volatile("v_fma_mix_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 32) asm volatile("v_mov_b32 %0, %1" : "+v"(x[i]) : "v"(a));
+                if (KIND == 33) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[i]) : "v"(a));
             }
         }
     }
@@ -44,7 +58,32 @@ __global__ void __launch_bounds__(256) k_rate(float* out, int iters, float a, fl
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+typedef float pk2 __attribute__((ext_vector_type(2)));
 template <int KIND>
+__global__ void __launch_bounds__(256) k_rate_pk(float* out, int iters, float a, float b) {
+    pk2 x[16];
+    pk2 a2 = {a, a + 1.f}, b2 = {b, b + 1.f};
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = pk2{(float)(threadIdx.x + i), (float)i};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (KIND == 0) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a2), "v"(b2));
+                if (KIND == 1) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a2));
+                if (KIND == 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a2));
+                if (KIND == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(x[i]) : "v"(a2), "v"(b2));
+                if (KIND == 4) asm volatile("v_pk_mov_b32 %0, %1, %2" : "+v"(x[i]) : "v"(a2), "v"(b2));
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += x[i].x + x[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int KIND, bool PK = false>
 void run(const char* name, int blocks_per_cu, float* d_out) {
     hipDeviceProp_t p;
     CHECK(hipGetDeviceProperties(&p, 0));
@@ -52,10 +91,10 @@ void run(const char* name, int blocks_per_cu, float* d_out) {
     const int blocks = cus * blocks_per_cu;                      // 256 threads = 4 waves = one wave per SIMD per block
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    k_rate<KIND><<<blocks, 256>>>(d_out, 10, 1.0001f, 0.5f);
+    if (PK) k_rate_pk<KIND><<<blocks, 256>>>(d_out, 10, 1.0001f, 0.5f); else k_rate<KIND><<<blocks, 256>>>(d_out, 10, 1.0001f, 0.5f);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    k_rate<KIND><<<blocks, 256>>>(d_out, iters, 1.0001f, 0.5f);
+    if (PK) k_rate_pk<KIND><<<blocks, 256>>>(d_out, iters, 1.0001f, 0.5f); else k_rate<KIND><<<blocks, 256>>>(d_out, iters, 1.0001f, 0.5f);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -90,6 +129,25 @@ int main() {
         run<17>("min3 x,a,0", w, d);
         run<18>("v_cmp_le sgpr", w, d);
         run<19>("cndmask sgpr", w, d);
+        run<20>("v_bfi_b32", w, d);
+        run<21>("v_and_or_b32", w, d);
+        run<22>("v_bfe_u32", w, d);
+        run<23>("v_lshrrev_b32", w, d);
+        run<24>("v_lshl_or_b32", w, d);
+        run<25>("v_min_u32", w, d);
+        run<26>("v_med3_f32", w, d);
+        run<27>("v_add_f32", w, d);
+        run<28>("v_or_b32", w, d);
+        run<29>("v_mad_u32_u24", w, d);
+        run<30>("v_add3_u32", w, d);
+        run<31>("v_fma_mix_f32", w, d);
+        run<32>("v_mov_b32", w, d);
+        run<33>("v_mov_dpp quad", w, d);
+        run<0, true>("v_pk_fma_f32", w, d);
+        run<1, true>("v_pk_mul_f32", w, d);
+        run<2, true>("v_pk_add_f32", w, d);
+        run<3, true>("pk_fma bcast", w, d);
+        run<4, true>("v_pk_mov_b32", w, d);
     }
     return 0;
 }
