@@ -199,6 +199,14 @@ int rt_flush(rt_ctx*);
 int rt_download_framebuffer(rt_ctx*, float* rgb, uint32_t* prim_id, rt_stats* stats);
 /* Same resolve, into DEVICE memory of the caller (img_w*img_h*3 floats), for RCCL gathers. */
 int rt_resolve_device(rt_ctx*, void* d_rgb);
+/* The displayable frame, in DEVICE memory of the caller (img_w*img_h RGBA8 pixels, alpha 255): the bytes main.cpp:251-253
+ * writes into rendu.ppm ((int)(255.f * std::min<float>(1.f, c)); values below 0, which the text file holds and a byte
+ * cannot, become 0), rows top to bottom like the PPM or, bottom_up != 0, bottom to top as glDrawPixels and GL textures
+ * want them. This is the device half of SURVEY 8(f).4 (a preview of the GPU frame in the GLUT window instead of
+ * write-PPM-then-view): d_rgba may be a GL pixel-buffer object mapped with hipGraphicsGLRegisterBuffer /
+ * hipGraphicsResourceGetMappedPointer (INTEGRATION.md shows the calls), or any other device pointer; with
+ * rt_continue_frame it shows the frame after every pass. With several devices the pointer belongs to device_ids[0]. */
+int rt_resolve_rgba8_device(rt_ctx*, void* d_rgba, int bottom_up);
 int rt_get_stats(rt_ctx*, rt_stats* stats);
 /* Diagnostic, no counterpart in the reference: 1 if the uploaded scene's shadow rays walk the 32-byte
  * quantised copies of the mesh nodes (all mesh boxes finite and nested, as bounding boxes of triangle

@@ -116,7 +116,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
 
 # every symbol include/rtgpu.h and include/rthost.h declare
 EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame", "rt_continue_frame",
-           "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_get_stats",
+           "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_resolve_rgba8_device", "rt_get_stats",
            "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion", "rt_filter_passes",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
            "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_build_mode", "rth_scene_desc",
@@ -153,6 +153,7 @@ def lib():
     L.rt_flush.argtypes = [vp]
     L.rt_download_framebuffer.argtypes = [vp, vp, vp, C.POINTER(Stats)]
     L.rt_resolve_device.argtypes = [vp, vp]
+    L.rt_resolve_rgba8_device.argtypes = [vp, vp, i32]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_uses_quantised_shadow_nodes.argtypes = [vp]
     L.rt_hit_excursion.argtypes = [vp, vp, vp, C.c_float]
@@ -421,6 +422,10 @@ class Context:
 
     def resolve_device(self, device_ptr):
         self._check(self.L.rt_resolve_device(self.h, C.c_void_p(device_ptr)), "rt_resolve_device")
+
+    def resolve_rgba8_device(self, device_ptr, bottom_up=False):
+        """The displayable frame (the PPM's bytes as RGBA8) into device memory of the caller, e.g. a mapped GL buffer."""
+        self._check(self.L.rt_resolve_rgba8_device(self.h, C.c_void_p(device_ptr), 1 if bottom_up else 0), "rt_resolve_rgba8_device")
 
     def render(self, cam, params, tiles=None):
         """Whole frame (or the given tiles): begin_frame, render_tile*, download."""

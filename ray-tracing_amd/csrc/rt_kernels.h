@@ -1760,6 +1760,25 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, const DiffuseRec* __re
     accumulate_runs(acc, nonfinite, ctr, slot, comp(thr, color), active);
 }
 
+/* The displayable frame: the bytes the reference writes into its PPM (main.cpp:251-253: (int)(255.f * std::min<float>(1.f, c)),
+ * where std::min keeps its first argument for a NaN), as RGBA8 with alpha 255; what the text file can hold and a byte
+ * cannot (negative values) is clamped to 0. Rows top to bottom like the PPM, or bottom-up for glDrawPixels / GL textures. */
+__global__ void __launch_bounds__(256) k_display(const float* __restrict__ rgb, int w, int h, int bottom_up, uint32_t* __restrict__ rgba) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)w * (uint32_t)h) return;
+    uint32_t px = 0xFF000000u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float c = rgb[3 * (size_t)i + k];
+        const float m = c < 1.f ? c : 1.f;                   /* std::min<float>(1.f, c): (c < 1.f) ? c : 1.f */
+        const float v = 255.f * m;
+        const uint32_t b = v >= 0.f ? (uint32_t)(int)v : 0u;
+        px |= b << (8 * k);
+    }
+    const uint32_t x = i % (uint32_t)w, y = i / (uint32_t)w;
+    rgba[(size_t)(bottom_up ? (uint32_t)h - 1u - y : y) * (uint32_t)w + x] = px;
+}
+
 __global__ void __launch_bounds__(256) k_resolve(const long long* acc, const uint32_t* nonfinite, uint32_t n_pix, int spp, float* rgb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pix * 3) return;

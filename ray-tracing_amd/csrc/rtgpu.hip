@@ -2112,6 +2112,21 @@ int rt_resolve_device(rt_ctx* c, void* d_rgb) {
     return RT_OK;
 }
 
+int rt_resolve_rgba8_device(rt_ctx* c, void* d_rgba, int bottom_up) {
+    if (!c || !d_rgba) return RT_ERR_ARG;
+    rt_ctx* d0 = c->subs.empty() ? c : c->subs[0];            /* the gathering device */
+    if (!d0->rgb.p) return fail(c, RT_ERR_STATE, "rt_resolve_rgba8_device before rt_begin_frame");
+    int rc = rt_resolve_device(c, d0->rgb.p);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(d0->device));
+    const uint32_t npix = (uint32_t)((size_t)c->fr.img_w * c->fr.img_h);
+    hipLaunchKernelGGL(k_display, dim3((npix + 255) / 256), dim3(256), 0, d0->stream, static_cast<const float*>(d0->rgb.p), c->fr.img_w, c->fr.img_h,
+                       bottom_up ? 1 : 0, static_cast<uint32_t*>(d_rgba));
+    HIP_TRY(c, hipStreamSynchronize(d0->stream));
+    HIP_TRY(c, hipGetLastError());
+    return RT_OK;
+}
+
 int rt_download_framebuffer(rt_ctx* c, float* rgb, uint32_t* prim_id, rt_stats* stats) {
     if (!c || !rgb) return RT_ERR_ARG;
     if (!c->subs.empty()) {
