@@ -40,17 +40,24 @@ __host__ __device__ inline uint32_t rt_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__host__ __device__ inline uint32_t rt_rng_impl(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code,
-                                                uint32_t light, uint32_t i, uint32_t which) {
+/* the rounds that only depend on the path (seed, pixel, sample, path code): one word per diffuse record, k_hash_records */
+__host__ __device__ inline uint32_t rt_rng_prefix(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code) {
     uint32_t h = rt_mix32(seed + 0x9e3779b9U);
     h = rt_mix32((h ^ pixel) + 0x9e3779b9U);
     h = rt_mix32((h ^ sample) + 0x9e3779b9U);
     h = rt_mix32((h ^ (uint32_t)code) + 0x9e3779b9U);
     h = rt_mix32((h ^ (uint32_t)(code >> 32)) + 0x9e3779b9U);
+    return h;
+}
+__host__ __device__ inline uint32_t rt_rng_tail(uint32_t h, uint32_t light, uint32_t i, uint32_t which) {
     h = rt_mix32((h ^ light) + 0x9e3779b9U);
     h = rt_mix32((h ^ i) + 0x9e3779b9U);
     h = rt_mix32((h ^ which) + 0x9e3779b9U);
     return h;
+}
+__host__ __device__ inline uint32_t rt_rng_impl(uint32_t seed, uint32_t pixel, uint32_t sample, uint64_t code,
+                                                uint32_t light, uint32_t i, uint32_t which) {
+    return rt_rng_tail(rt_rng_prefix(seed, pixel, sample, code), light, i, which);
 }
 
 /* ---------------------------------------------------------------- device scene */

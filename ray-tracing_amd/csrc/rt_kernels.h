@@ -741,6 +741,15 @@ RT_DEV void locate_sample(const TileD* tiles, int n_tiles, const FrameD& fr, uns
     }
     TileD t = tiles[lo];
     unsigned long long local = k - t.first;
+    /* (a 64-bit division costs about 150 instructions, a 32-bit one 25: the samples of one tile almost always fit 32 bits) */
+    if ((local >> 32) == 0ull) {
+        const uint32_t l32 = (uint32_t)local, pix = l32 / (uint32_t)fr.spp;
+        s = fr.sample_base + (int)(l32 - pix * (uint32_t)fr.spp);
+        const uint32_t row = pix / (uint32_t)t.w;
+        x = t.x0 + (int)(pix - row * (uint32_t)t.w);
+        y = t.y0 + (int)row;
+        return;
+    }
     unsigned long long pix = local / (unsigned)fr.spp;
     s = fr.sample_base + (int)(local % (unsigned)fr.spp);
     x = t.x0 + (int)(pix % (unsigned)t.w);
@@ -1434,19 +1443,27 @@ RT_DEV void shadow_quant_exact_step(const DScene& sc, ShadowLane& s, uint32_t* c
 /* the shadow ray of (record, light, sample) number idx */
 RT_DEV void shadow_ray_of(const DScene& sc, const FrameD& fr, const DiffuseRec* __restrict__ drec, const unsigned long long* __restrict__ dcode,
                           unsigned long long idx, int S, uint32_t& key_out, F3& o_out, F3& d_out, float& dist_out) {
-    uint32_t key = (uint32_t)(idx / (unsigned)S);
-    uint32_t i = (uint32_t)(idx % (unsigned)S);
-    uint32_t rec = key / (uint32_t)sc.n_lights, li = key % (uint32_t)sc.n_lights;
+    uint32_t key, i;
+    if ((idx >> 32) == 0ull) {               /* (the rays of one launch almost always fit 32 bits: a quarter of the 64-bit division's instructions) */
+        key = (uint32_t)idx / (uint32_t)S;
+        i = (uint32_t)idx - key * (uint32_t)S;
+    } else {
+        key = (uint32_t)(idx / (unsigned)S);
+        i = (uint32_t)(idx % (unsigned)S);
+    }
+    uint32_t rec = key, li = 0u;
+    if (sc.n_lights != 1) { rec = key / (uint32_t)sc.n_lights; li = key - rec * (uint32_t)sc.n_lights; }
     const float4* q = reinterpret_cast<const float4*>(drec + rec);
-    float4 q0 = q[0], q3 = q[3];
+    float4 q0 = q[0];
     F3 P = f3(q0.x, q0.y, q0.z);
     DLight L = sc.lights[li];
     F3 lp = f3(L.pos[0], L.pos[1], L.pos[2]);
     if (fr.shadow_mode == 0) {
-        uint32_t pixel = __float_as_uint(q3.z), sample = __float_as_uint(q3.w);
-        unsigned long long code = dcode[rec];
-        uint32_t ky = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 0) % 360u;   /* randY first, Scene.h:115 */
-        uint32_t kx = rt_rng_impl(fr.seed, pixel, sample, code, li, i, 1) % 360u;
+        /* rt_rng(seed, pixel, sample, code, light, i, which): the rounds over the first four arguments were run once per
+         * record (k_hash_records left them in the low word of the record's code slot), the last three differ per ray */
+        const uint32_t h = (uint32_t)dcode[rec];
+        uint32_t ky = rt_rng_tail(h, li, i, 0) % 360u;   /* randY first, Scene.h:115 */
+        uint32_t kx = rt_rng_tail(h, li, i, 1) % 360u;
         double sinY = sc.sincos[ky], cosY = sc.sincos[360 + ky];
         double sinX = sc.sincos[kx], cosX = sc.sincos[360 + kx];
         float p1 = (float)(-sinY), p2 = (float)cosY;                                 /* Scene.h:119 */
@@ -1460,6 +1477,14 @@ RT_DEV void shadow_ray_of(const DScene& sc, const FrameD& fr, const DiffuseRec* 
     F3 o = add(P, mul(0.001f, dir));
     F3 d = normalized(dir);                                                          /* Line.h:15 */
     key_out = key; o_out = o; d_out = d; dist_out = lightDistance;
+}
+/* per diffuse record: its path code (8 bytes, written by k_closest) gives way to the state of the counter RNG after the
+ * rounds that the record's 35 x lights shadow rays share; runs once per batch, before the kernels that make shadow rays */
+__global__ void __launch_bounds__(256) k_hash_records(uint32_t seed, const DiffuseRec* __restrict__ drec, unsigned long long* dcode, uint32_t n_rec) {
+    const uint32_t rec = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rec >= n_rec) return;
+    const float4 q3 = reinterpret_cast<const float4*>(drec + rec)[3];
+    dcode[rec] = (unsigned long long)rt_rng_prefix(seed, __float_as_uint(q3.z), __float_as_uint(q3.w), dcode[rec]);
 }
 __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
                                                       const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,

@@ -394,6 +394,8 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         if (n_diff && L > 0) {
             HIP_TRY(c, hipMemsetAsync(w.cnt, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
             const unsigned long long per_rec = (unsigned long long)L * S;
+            if (c->fr.shadow_mode == 0)
+                hipLaunchKernelGGL(k_hash_records, dim3((n_diff + 255) / 256), dim3(256), 0, c->stream, c->fr.seed, w.drec, w.dcode, n_diff);
             /* no meshes: one thread per ray from record to verdict (k_shadow_direct), no ray buffer, no persistent kernel */
             const bool direct = c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW");
             if (direct) {

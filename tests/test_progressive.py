@@ -52,9 +52,9 @@ def test_displayable_frame_is_the_ppm_bytes(rt, ctx, scene):
     """rt_resolve_rgba8_device (the device half of SURVEY 8(f).4): RGBA8 in caller-owned device memory = the bytes of the PPM
     (main.cpp:251-253), top-down or bottom-up, after every progressive pass."""
     import ctypes
-    import os
-    # caller-owned device memory straight from the HIP runtime the library itself uses (same file, same handle)
-    hip = ctypes.CDLL(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"))
+    # caller-owned device memory straight from the HIP runtime the library itself uses: by soname, so that the copy
+    # librtgpu.so is already bound to comes back (/opt/rocm's, or torch's bundled one if torch was imported first)
+    hip = ctypes.CDLL("libamdhip64.so.7")
     hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
