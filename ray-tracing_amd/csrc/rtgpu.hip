@@ -459,6 +459,8 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                 const int top_lds = ((size_t)c->sc.top_blob_bytes <= top_room && !getenv("RT_TOP_GLOBAL")) ? 1 : 0;
                 int lds_cap = 0;
                 const int ovf_cap = wide_ovf_cap(c, &lds_cap);
+                if (c->debug && r0 == 0 && c->stats.iterations == 0)
+                    fprintf(stderr, "[rtgpu] k_shadow: %zu bytes of LDS stacks per wave, top-level tables %d bytes -> %s\n", lds, c->sc.top_blob_bytes, top_lds ? "LDS" : "global memory");
                 if ((size_t)std::max<unsigned long long>(blocks, blocks_now) * ovf_cap * RT_BLOCK * sizeof(int) > w.ovf_bytes)
                     return fail(c, RT_ERR_LIMIT, "spill buffer of the shadow walk too small (%d entries per lane)", ovf_cap);
                 int top_min = c->sc.n_top_items >= 24 ? 32 : 1;       /* see k_shadow; measured on the default scene: 1, 8, 16, 32, 48, 60 -> 2365, 2205, 2065, 1828, 1839, 2111 ms */
