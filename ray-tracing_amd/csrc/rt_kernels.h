@@ -1017,6 +1017,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 16      /* refill once this many lanes are idle (4 / 8 / 16 / 24 / 32: 229.7 / 219.7 / 215.3 / 223.8 / 240.3 ms on the reduced C5 frame; gorilla, cow, chamber -2..3 % at 16) */
 #endif
+#ifndef RT_REFILL_MIN_SUB
+#define RT_REFILL_MIN_SUB 32   /* ... in the variant with sub-trees in fat leaves (short walks; 16 / 24 / 28 / 32 / 40: gorilla 40.4 / 39.5 / 39.2 / 39.2 / 39.5 ms, cow 27.0 / 26.6 / 26.2 / 26.0 / 26.1, mirror chamber 101.1 / 99.0 / 98.9 / 98.5 / 99.5; the many-object variant prefers 16) */
+#endif
 #ifndef RT_GRAB
 #define RT_GRAB 512u           /* rays a wave takes from the global counter at a time */
 #endif
@@ -1642,7 +1645,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     for (;;) {
         if (count_steps) k_t0 = __builtin_readcyclecounter();
         unsigned long long idle = __builtin_amdgcn_ballot_w64(s.st == ST_IDLE);
-        if ((!exhausted || wpos < wend) && (__popcll(idle) >= RT_REFILL_MIN)) {
+        if ((!exhausted || wpos < wend) && (__popcll(idle) >= (MODE == 2 ? RT_REFILL_MIN_SUB : RT_REFILL_MIN))) {
             /* ray indices come from a wave-local range [wpos, wend) that is topped up RT_GRAB rays at a time: one
              * atomic on the single global counter per RT_GRAB rays instead of one per refill (same-address
              * device-scope atomics serialise) */
