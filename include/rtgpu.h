@@ -160,7 +160,11 @@ typedef struct {
 /* Creates a context on the n_devices GPUs of device_ids (1 <= n_devices <= 64; the ThreadPool of main.cpp:204-205, as GPUs).
  * One device: everything runs there. Several: the scene is replicated, rt_render_tile deals the tiles (round-robin along a
  * tile row with a hashed offset per row), rt_flush drives every device from a host thread of its own, and the frame is
- * gathered on device_ids[0] (packed tile slabs, hipMemcpyPeerAsync, scatter) -- rt_resolve_device's buffer lives there.
+ * gathered on device_ids[0] -- rt_resolve_device's buffer lives there: every device packs the pixels of its tiles into a slab
+ * on its own stream, device_ids[0] pulls all slabs behind their events (hipMemcpyPeerAsync; rt_init enables peer access and
+ * says so on stderr where it cannot, the copies then stage through host memory) and scatters them with one kernel. The
+ * gather covers the tiles of the whole FRAME (all passes since rt_begin_frame), so a progressive pass over some tiles
+ * only, or a resolve right after rt_continue_frame, still returns what the other devices rendered earlier.
  * The frame has the bits of a one-device render. rt_intersect / rt_occluded / rt_trace* run on device_ids[0].
  * (Scaling across processes -- one process per GPU, RCCL -- is ray-tracing_amd/dist.py + bench.py.) */
 int rt_init(const int* device_ids, int n_devices, rt_ctx** out);
@@ -231,9 +235,11 @@ int rt_occluded(rt_ctx*, const float* pts, const float* light_pos, int64_t n, in
 /* Scene::rayTrace (Scene.h:283-286) on n rays; pixel/sample key the light-sampling RNG. */
 int rt_trace(rt_ctx*, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample,
              int64_t n, const rt_render_params*, float* rgb);
-/* rt_trace for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc). No counterpart in the reference. Same arguments, same radiance bits as rt_trace, but it calls no hipMalloc /
- * hipFree / hipEventCreate: staging, path states, queues, counters, shadow rays and the spill slices of the shadow walk
+/* rt_trace for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that must not disturb
+ * a caching allocator). No counterpart in the reference. Same arguments, same radiance bits as rt_trace, but it calls no
+ * hipMalloc / hipFree / hipEventCreate. It is NOT capturable into a HIP graph: like rt_trace it copies from and to the
+ * caller's host arrays and synchronises the context's stream after every iteration of the wavefront loop (the host reads
+ * the queue counters back to size the next launches). Staging, path states, queues, counters, shadow rays and the spill slices of the shadow walk
  * live in a file-scope __device__ array of RT_STATIC_BYTES = 8 MiB that every GPU the library runs on holds until the
  * process ends (address taken once per context, in rt_init). Limits (RT_ERR_LIMIT beyond them): n <= RT_STATIC_MAX_RAYS,
  * max_depth <= RT_STATIC_MAX_DEPTH, lights x light_samples <= 65536, and a scene whose 4-wide shadow walk spills at

@@ -97,6 +97,7 @@ public:
     void rotate_x(float angle);                         /* Mesh.h:151-157 */
     void rotate_y(float angle);                         /* Mesh.h:159-165 */
     void rotate_z(float angle);                         /* Mesh.h:167-173 */
+    void unweld();                                      /* every triangle gets vertices of its own (face normals after recomputeNormals); no counterpart in the reference */
     void build_arrays() { recomputeNormals(); }         /* Mesh.h:119-125 (GL arrays not needed) */
     void buildTree(unsigned nb_of_subdivide_tree, int tree_mode = 0);      /* Mesh.cpp:144-179; tree_mode: Settings::tree_mode */
     AABB getBoundingBox() const { return triangleTree.rootBox; }   /* Mesh.cpp:181-183 */
@@ -166,6 +167,7 @@ public:
     int loadImage(const std::string& relative_path);
     int addImage(int width, int height, int channels, const uint8_t* texels);
     bool setup_mesh_scene(const std::string& off, bool unit);   /* Scene.h:716-781 (gorilla block) */
+    bool setup_stage_scene(const std::string& off, bool flat, float scale, float rotx, const Vec3& move);   /* the scenes of the stage images with.ppm, without.ppm and gorilla_1.ppm (scene.cpp) */
     bool setup_soup_scene(int64_t ntris);               /* BASELINE config 5 */
     bool setup(const std::string& name);
 

@@ -925,6 +925,34 @@ int setup_mesh_scene(orc_scene& sc, const char* file, bool unit) {
     return 0;
 }
 
+/* The scenes of the reference's committed stage images etapes/normal_interpolation/{with,without}.ppm and
+ * etapes/mesh/gorilla_1.ppm: the room of setup_test_scene (Scene.h:733-756) around one white mesh, as the author's tree
+ * had it when those frames were written. The reference no longer holds those blocks (what is left is the commented-out
+ * mesh block of Scene.h:758-781), so the values below that are not in Scene.h were RECOVERED FROM THE IMAGES
+ * (tests/golden/make_fixtures.py says how): the light sat at (0, 3.5, 0) -- the position of Scene.h:477 -- and cast hard
+ * shadows (Scene.h:215, isInShadow, before sampleSphereLight replaced it); the blob of assets/models/blob.off was turned
+ * upside down (rotate_x(180)) and moved by (-0.125, -1.05, -1.25). `flat`: every triangle gets vertices of its own, so that
+ * recomputeNormals leaves it its face normal (without.ppm was written before normal interpolation existed). */
+void unweld(MeshObj& m) {
+    std::vector<V3> pos(m.tri.size());
+    for (size_t i = 0; i < m.tri.size(); i++) { pos[i] = m.pos[m.tri[i]]; m.tri[i] = (uint32_t)i; }
+    m.pos.swap(pos);
+}
+int setup_stage_scene(orc_scene& sc, const char* file, bool flat, float scale, float rotx, const V3& move) {
+    test_scene_room(sc);
+    sc.lights[0] = make_light(V3(0.0f, 3.5f, 0.0f), 0.f);
+    sc.meshes.emplace_back();
+    MeshObj& m = sc.meshes.back();
+    if (!add_off_mesh(sc, file, m)) return -2;
+    if (scale != 1.f) apply_matrix(m.pos, m.pos.size(), scale_matrix(V3(scale)));
+    if (rotx != 0.f) apply_matrix(m.pos, m.pos.size(), rot_x(rotx));
+    translate(m.pos, m.pos.size(), move);
+    if (flat) unweld(m);
+    recompute_normals(m);
+    m.mat.kd = V3(1.f, 1.f, 1.f); m.mat.ks = V3(1.f, 1.f, 1.f); m.mat.shininess = 16;
+    return 0;
+}
+
 /* Scene::setup_reflexion_chamber, Scene.h:601-714: six walls (five mirrors, a checker floor with the normal map
  * n3.ppm), two small lights, a flamingo. */
 int setup_reflexion_chamber(orc_scene& sc) {
@@ -1302,6 +1330,9 @@ int orc_scene_setup(orc_scene* sc, const char* name) {
     if (n == "reflexion") return setup_reflexion(*sc);
     if (n == "mesh_gorilla") return setup_mesh_scene(*sc, "gorilla18_fixed.obj.off", false);
     if (n == "mesh_cow") return setup_mesh_scene(*sc, "cow.off", true);
+    if (n == "stage_blob") return setup_stage_scene(*sc, "blob.off", false, 1.f, 180.f, V3(-0.125f, -1.05f, -1.25f));
+    if (n == "stage_blob_flat") return setup_stage_scene(*sc, "blob.off", true, 1.f, 180.f, V3(-0.125f, -1.05f, -1.25f));
+    if (n == "stage_gorilla") return setup_stage_scene(*sc, "gorilla18_fixed.obj.off", false, 0.0125f, 0.f, V3(0.f, -1.05f, 0.f));
     if (n == "reflexion_chamber") return setup_reflexion_chamber(*sc);
     if (n == "cornell_box") return setup_cornell_box(*sc);
     if (n.rfind("soup:", 0) == 0) return setup_soup(*sc, atoll(n.c_str() + 5));

@@ -651,6 +651,30 @@ bool Scene::setup_mesh_scene(const std::string& off, bool unit) {
     return true;
 }
 
+/* The scenes of the reference's stage images etapes/normal_interpolation/{with,without}.ppm and etapes/mesh/gorilla_1.ppm:
+ * the room of setup_test_scene (Scene.h:733-756) around one white mesh. Light position (that of Scene.h:477), hard shadows
+ * and the blob's transformation are not in the reference any more; they were recovered from the images
+ * (tests/golden/make_fixtures.py). `flat`: per-triangle vertices, i.e. face normals (without.ppm predates Mesh.cpp:117-130). */
+void Mesh::unweld() {
+    std::vector<Vec3> pos(triangles.size());
+    for (size_t i = 0; i < triangles.size(); i++) { pos[i] = positions[triangles[i]]; triangles[i] = (uint32_t)i; }
+    positions.swap(pos);
+}
+bool Scene::setup_stage_scene(const std::string& off, bool flat, float scale, float rotx, const Vec3& move) {
+    if (!setup_mesh_scene(off, false)) return false;        /* (the room; the mesh is replaced below) */
+    lights[0] = pointLight(0.0f, 3.5f, 0.0f, 0.f);
+    Mesh& m = meshes.back();
+    if (!m.loadOFF(g_asset_dir + "/" + off)) return false;
+    if (scale != 1.f) m.scale(Vec3(scale));
+    if (rotx != 0.f) m.rotate_x(rotx);
+    m.translate(move);
+    if (flat) m.unweld();
+    m.build_arrays();
+    m.buildTree(3);
+    buildSceneBvh();
+    return true;
+}
+
 /* Scene::setup_reflexion_chamber, Scene.h:601-714 */
 bool Scene::setup_reflexion_chamber() {
     clear();
@@ -1035,6 +1059,9 @@ bool Scene::setup(const std::string& name) {
     if (name == "reflexion") return setup_reflexion_scene();
     if (name == "mesh_gorilla") return setup_mesh_scene("gorilla18_fixed.obj.off", false);
     if (name == "mesh_cow") return setup_mesh_scene("cow.off", true);
+    if (name == "stage_blob") return setup_stage_scene("blob.off", false, 1.f, 180.f, Vec3(-0.125f, -1.05f, -1.25f));
+    if (name == "stage_blob_flat") return setup_stage_scene("blob.off", true, 1.f, 180.f, Vec3(-0.125f, -1.05f, -1.25f));
+    if (name == "stage_gorilla") return setup_stage_scene("gorilla18_fixed.obj.off", false, 0.0125f, 0.f, Vec3(0.f, -1.05f, 0.f));
     if (name == "reflexion_chamber") return setup_reflexion_chamber();
     if (name == "cornell_box") return setup_cornell_box();
     if (name.rfind("soup:", 0) == 0) return setup_soup_scene(atoll(name.c_str() + 5));

@@ -27,6 +27,8 @@
 #include <cstring>
 #include <functional>
 #include <new>
+#include <set>
+#include <tuple>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -90,8 +92,11 @@ struct rt_ctx {
     /* a context over several GPUs (rt_init with n_devices > 1): one full context per device; this one only deals the tiles
      * and gathers the frame on subs[0]'s device */
     std::vector<rt_ctx*> subs;
-    std::vector<std::vector<TileD>> sub_tiles;     /* per device: the tiles of this frame, `first` counted in PIXELS */
-    DevBuf mg_slab, mg_tiles;                      /* on subs[0]'s device: packed pixels / tile list of one other device */
+    std::vector<std::vector<TileD>> sub_tiles;     /* per device: the tiles of this FRAME (the union over its progressive passes, each rectangle once), `first` counted in PIXELS */
+    std::vector<std::set<std::tuple<int, int, int, int>>> sub_tile_keys;     /* ... the rectangles already in sub_tiles */
+    std::vector<TileD> mg_all;                     /* the gathered tiles of all other devices, `first` counted along the concatenated slabs */
+    DevBuf mg_slab, mg_tiles;                      /* on subs[0]'s device: the packed pixels of all other devices, one slab after the other / their tile list; on a rendering device: its own slab / tiles */
+    hipEvent_t ev_pack = nullptr;                  /* (per device) this device's slab is packed */
     unsigned char* static_scratch = nullptr;   /* this device's copy of rt_static_scratch (rt_trace_static) */
 };
 
@@ -1125,6 +1130,27 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
             p->subs.push_back(sub);
         }
         p->sub_tiles.resize((size_t)n_devices);
+        p->sub_tile_keys.resize((size_t)n_devices);
+        /* the gather pulls every other device's slab over xGMI: ask for peer access from the gathering device (and back); without it
+         * hipMemcpyPeerAsync still works but stages through host memory -- said once, not silently */
+        for (int k = 1; k < n_devices; k++) {
+            const int d0 = device_ids[0], dk = device_ids[k];
+            if (dk == d0) continue;
+            bool done = false;
+            for (int j = 1; j < k; j++) if (device_ids[j] == dk) done = true;
+            if (done) continue;
+            int can = 0, back = 0;
+            bool ok = hipDeviceCanAccessPeer(&can, d0, dk) == hipSuccess && can && hipDeviceCanAccessPeer(&back, dk, d0) == hipSuccess && back;
+            if (ok) {
+                hipError_t e1 = hipSetDevice(d0) == hipSuccess ? hipDeviceEnablePeerAccess(dk, 0) : hipErrorInvalidDevice;
+                hipError_t e2 = hipSetDevice(dk) == hipSuccess ? hipDeviceEnablePeerAccess(d0, 0) : hipErrorInvalidDevice;
+                ok = (e1 == hipSuccess || e1 == hipErrorPeerAccessAlreadyEnabled) && (e2 == hipSuccess || e2 == hipErrorPeerAccessAlreadyEnabled);
+                (void)hipGetLastError();
+            }
+            if (!ok) fprintf(stderr, "[rtgpu] no peer access between devices %d and %d: the frame gather stages their slab through host memory\n", d0, dk);
+            else if (getenv("RT_DEBUG")) fprintf(stderr, "[rtgpu] peer access between devices %d and %d enabled\n", d0, dk);
+        }
+        (void)hipSetDevice(device_ids[0]);
         *out = p;
         return RT_OK;
     }
@@ -1134,7 +1160,7 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
     rt_ctx* c = new rt_ctx();
     c->device = dev;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev_frame_a) != hipSuccess ||
-        hipEventCreate(&c->ev_frame_b) != hipSuccess) {
+        hipEventCreate(&c->ev_frame_b) != hipSuccess || hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return RT_ERR_DEVICE;
     }
@@ -1176,11 +1202,12 @@ void rt_shutdown(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
-    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf, &c->srays, &c->dtex, &c->ovf}) release(*b);
+    for (DevBuf* b : {&c->acc, &c->nf, &c->prim, &c->rgb, &c->stack, &c->child, &c->drec, &c->dcode, &c->cnt, &c->ctr, &c->tilebuf, &c->srays, &c->dtex, &c->ovf, &c->mg_slab, &c->mg_tiles}) release(*b);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     for (EventPair& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     (void)hipEventDestroy(c->ev_frame_a);
     (void)hipEventDestroy(c->ev_frame_b);
+    if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1789,7 +1816,9 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     sc.has_topsub = has_topsub ? 1 : 0;
     {   /* contribution culling (k_closest): the bound needs finite, non-negative light colours */
         double sum = 0.0;
-        bool ok = !getenv("RT_NO_CULL");
+        /* without lights the reference's shadow factor is 1 - 0/0 = NaN on every diffuse hit (Scene.h:211-222), whatever its throughput:
+         * nothing may be culled, or those NaNs would not reach the frame */
+        bool ok = !getenv("RT_NO_CULL") && d->n_lights > 0;
         for (int i = 0; i < d->n_lights; i++) {
             double mx = 0.0;
             for (int k = 0; k < 3; k++) { const double v = std::fabs((double)d->lights[i].color[k]); if (!(v < 1e30)) ok = false; mx = std::max(mx, v); }
@@ -1800,6 +1829,25 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
          * materials; needs finite geometry (a NaN normal below a culled state would have reached the frame as a NaN) */
         bool states = ok;
         for (int64_t i = 0; i < 3 * d->n_verts && states; i++) if (!(std::fabs(d->normals[i]) < 1e30f) || !(std::fabs(d->positions[i]) < 1e30f)) states = false;
+        /* ... and an interpolated normal that can vanish (Mesh.cpp:117-130 normalises n0 w0 + n1 w1 + n2 w2: 0/0 = NaN): a vertex normal of
+         * length zero, or two normals of one triangle that point against each other */
+        for (int64_t v = 0; v < d->n_verts && states; v++) {
+            const float* n = d->normals + 3 * v;
+            if (!((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2] > 1e-60)) states = false;
+        }
+        for (int mi = 0; mi < d->n_meshes && states; mi++) {
+            const rt_mesh& m = d->meshes[mi];
+            for (int64_t t = 0; t < m.tri_count && states; t++) {
+                const float* nv[3];
+                for (int k = 0; k < 3; k++) nv[k] = d->normals + 3 * ((int64_t)m.vert_first + (int64_t)d->tri_indices[3 * (m.tri_first + t) + k]);
+                for (int k = 0; k < 3 && states; k++) {
+                    const float* a = nv[k]; const float* b = nv[(k + 1) % 3];
+                    const double ab = (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2];
+                    const double aa = (double)a[0] * a[0] + (double)a[1] * a[1] + (double)a[2] * a[2], bb = (double)b[0] * b[0] + (double)b[1] * b[1] + (double)b[2] * b[2];
+                    if (!(ab > -0.9999 * std::sqrt(aa * bb))) states = false;
+                }
+            }
+        }
         double G = 1.0, Cm = 1.0;                        /* the sky adds at most 1 per unit (Scene.h:274-278) */
         for (int i = 0; i < d->n_materials && states; i++) {
             const rt_material& m = d->materials[i];
@@ -1948,6 +1996,7 @@ int rt_begin_frame(rt_ctx* c, const rt_render_params* p) {
         if (rc) return rc;
         set_frame(c, p);
         for (auto& t : c->sub_tiles) t.clear();
+        for (auto& t : c->sub_tile_keys) t.clear();
         memset(&c->stats, 0, sizeof(c->stats));
         c->has_frame = true;
         return RT_OK;
@@ -1982,7 +2031,8 @@ int rt_continue_frame(rt_ctx* c, int32_t more_spp) {
     if (!c->subs.empty()) {
         rc = on_all(c, [&](rt_ctx* q) { return rt_continue_frame(q, more_spp); });
         if (rc) return rc;
-        for (auto& t : c->sub_tiles) t.clear();
+        /* (sub_tiles stays: it lists the tiles of the FRAME -- a later pass may cover only some of them, and the gather must still
+         * bring home what the earlier passes rendered on the other devices; rt_begin_frame clears it) */
     } else {
         c->tiles.clear();
         c->queued_samples = 0;
@@ -1999,7 +2049,7 @@ int rt_render_tile(rt_ctx* c, int x0, int y0, int w, int h) {
         const int k = tile_owner(std::max(x0, 0), std::max(y0, 0), (int)c->subs.size());
         int rc = rt_render_tile(c->subs[(size_t)k], x0, y0, w, h);
         if (rc) return fail(c, rc, "%s", c->subs[(size_t)k]->err.c_str());
-        if (w > 0 && h > 0) {
+        if (w > 0 && h > 0 && c->sub_tile_keys[(size_t)k].insert(std::make_tuple(x0, y0, w, h)).second) {
             std::vector<TileD>& tl = c->sub_tiles[(size_t)k];
             TileD t;
             t.x0 = x0; t.y0 = y0; t.w = w; t.h = h;
@@ -2074,33 +2124,54 @@ int rt_resolve_device(rt_ctx* c, void* d_rgb) {
         int rc = rt_flush(c);
         if (rc) return rc;
         rt_ctx* d0 = c->subs[0];
-        if ((rc = rt_resolve_device(d0, d_rgb))) return fail(c, rc, "%s", d0->err.c_str());
+        /* all devices at once, each on its own host thread and stream: resolve; the others also pack the pixels of their tiles
+         * into a slab and record an event behind it */
         rc = on_all(c, [&](rt_ctx* q) -> int {
-            if (q == d0) return RT_OK;
+            if (q == d0) return rt_resolve_device(d0, d_rgb);
             int r2 = rt_resolve_device(q, q->rgb.p);
-            return r2;
-        });
-        if (rc) return rc;
-        for (size_t k = 1; k < c->subs.size(); k++) {
-            rt_ctx* q = c->subs[k];
+            if (r2) return r2;
+            size_t k = 0;
+            while (c->subs[k] != q) k++;
             const std::vector<TileD>& tl = c->sub_tiles[k];
-            if (tl.empty()) continue;
+            if (tl.empty()) return RT_OK;
             const uint32_t n_pix = (uint32_t)(tl.back().first + (unsigned long long)tl.back().w * tl.back().h);
-            /* pack on the device that rendered */
-            HIP_TRY(c, hipSetDevice(q->device));
-            if ((rc = ensure(q, q->mg_slab, (size_t)n_pix * 12)) || (rc = ensure(q, q->mg_tiles, tl.size() * sizeof(TileD)))) return fail(c, rc, "%s", q->err.c_str());
-            HIP_TRY(c, hipMemcpyAsync(q->mg_tiles.p, tl.data(), tl.size() * sizeof(TileD), hipMemcpyHostToDevice, q->stream));
+            HIP_TRY(q, hipSetDevice(q->device));
+            if ((r2 = ensure(q, q->mg_slab, (size_t)n_pix * 12)) || (r2 = ensure(q, q->mg_tiles, tl.size() * sizeof(TileD)))) return r2;
+            HIP_TRY(q, hipMemcpyAsync(q->mg_tiles.p, tl.data(), tl.size() * sizeof(TileD), hipMemcpyHostToDevice, q->stream));
             hipLaunchKernelGGL(k_tiles_pack, dim3((n_pix + 255) / 256), dim3(256), 0, q->stream, static_cast<const float*>(q->rgb.p), c->fr.img_w,
                                static_cast<const TileD*>(q->mg_tiles.p), (int)tl.size(), n_pix, static_cast<float*>(q->mg_slab.p));
-            HIP_TRY(c, hipStreamSynchronize(q->stream));
-            /* move and scatter on the gathering device */
+            HIP_TRY(q, hipEventRecord(q->ev_pack, q->stream));
+            return RT_OK;
+        });
+        if (rc) return rc;
+        /* the gathering device pulls every slab behind its event (peer copies over xGMI, all queued at once) into one
+         * buffer, slab after slab, and scatters them with ONE kernel over the merged tile list */
+        c->mg_all.clear();
+        unsigned long long total = 0;
+        for (size_t k = 1; k < c->subs.size(); k++) {
+            const std::vector<TileD>& tl = c->sub_tiles[k];
+            if (tl.empty()) continue;
+            for (TileD t : tl) { t.first += total; c->mg_all.push_back(t); }
+            total += tl.back().first + (unsigned long long)tl.back().w * tl.back().h;
+        }
+        if (total) {
             HIP_TRY(c, hipSetDevice(d0->device));
-            if ((rc = ensure(c, c->mg_slab, (size_t)n_pix * 12)) || (rc = ensure(c, c->mg_tiles, tl.size() * sizeof(TileD)))) return rc;
-            if (q->device == d0->device) HIP_TRY(c, hipMemcpyAsync(c->mg_slab.p, q->mg_slab.p, (size_t)n_pix * 12, hipMemcpyDeviceToDevice, d0->stream));
-            else HIP_TRY(c, hipMemcpyPeerAsync(c->mg_slab.p, d0->device, q->mg_slab.p, q->device, (size_t)n_pix * 12, d0->stream));
-            HIP_TRY(c, hipMemcpyAsync(c->mg_tiles.p, tl.data(), tl.size() * sizeof(TileD), hipMemcpyHostToDevice, d0->stream));
-            hipLaunchKernelGGL(k_tiles_scatter, dim3((n_pix + 255) / 256), dim3(256), 0, d0->stream, static_cast<float*>(d_rgb), c->fr.img_w,
-                               static_cast<const TileD*>(c->mg_tiles.p), (int)tl.size(), n_pix, static_cast<const float*>(c->mg_slab.p));
+            if ((rc = ensure(c, c->mg_slab, (size_t)total * 12)) || (rc = ensure(c, c->mg_tiles, c->mg_all.size() * sizeof(TileD)))) return rc;
+            unsigned long long off = 0;
+            for (size_t k = 1; k < c->subs.size(); k++) {
+                rt_ctx* q = c->subs[k];
+                const std::vector<TileD>& tl = c->sub_tiles[k];
+                if (tl.empty()) continue;
+                const unsigned long long n_pix = tl.back().first + (unsigned long long)tl.back().w * tl.back().h;
+                unsigned char* dst = static_cast<unsigned char*>(c->mg_slab.p) + (size_t)off * 12;
+                HIP_TRY(c, hipStreamWaitEvent(d0->stream, q->ev_pack, 0));
+                if (q->device == d0->device) HIP_TRY(c, hipMemcpyAsync(dst, q->mg_slab.p, (size_t)n_pix * 12, hipMemcpyDeviceToDevice, d0->stream));
+                else HIP_TRY(c, hipMemcpyPeerAsync(dst, d0->device, q->mg_slab.p, q->device, (size_t)n_pix * 12, d0->stream));
+                off += n_pix;
+            }
+            HIP_TRY(c, hipMemcpyAsync(c->mg_tiles.p, c->mg_all.data(), c->mg_all.size() * sizeof(TileD), hipMemcpyHostToDevice, d0->stream));
+            hipLaunchKernelGGL(k_tiles_scatter, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, d0->stream, static_cast<float*>(d_rgb), c->fr.img_w,
+                               static_cast<const TileD*>(c->mg_tiles.p), (int)c->mg_all.size(), (uint32_t)total, static_cast<const float*>(c->mg_slab.p));
             HIP_TRY(c, hipStreamSynchronize(d0->stream));
         }
         HIP_TRY(c, hipGetLastError());
@@ -2108,6 +2179,7 @@ int rt_resolve_device(rt_ctx* c, void* d_rgb) {
     }
     int rc = rt_flush(c);
     if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));        /* (rt_flush returns before its own hipSetDevice when nothing is queued, and this may run on a worker thread of on_all) */
     uint32_t npix = (uint32_t)((size_t)c->fr.img_w * c->fr.img_h);
     hipLaunchKernelGGL(k_resolve, dim3((npix * 3 + 255) / 256), dim3(256), 0, c->stream, static_cast<const long long*>(c->acc.p),
                        static_cast<const uint32_t*>(c->nf.p), npix, c->fr.sample_base + c->fr.spp, static_cast<float*>(d_rgb));

@@ -74,7 +74,7 @@ def compare_scene(hs, os_):
 
 
 @pytest.mark.parametrize("name,depth", [("final", 12), ("final", 3), ("refraction", 12), ("reflexion", 12), ("reflexion_chamber", 12), ("cornell_box", 12), ("mesh_gorilla", 12),
-                                        ("mesh_cow", 16), ("soup:30000", 12), ("soup:30000", 20)])
+                                        ("mesh_cow", 16), ("soup:30000", 12), ("soup:30000", 20), ("stage_blob", 12), ("stage_blob_flat", 12), ("stage_gorilla", 12)])
 def test_named_scenes_flatten_like_the_oracle(rt, name, depth):
     compare_scene(rt.HostScene(name, 3, depth), O.Scene(name, 3, depth))
 

@@ -52,6 +52,24 @@ def test_two_sub_contexts_give_the_one_device_frame(ctx, name, depth):
             multi.render_tile(*t)
         got3, gprim3, _ = multi.download()
         assert np.array_equal(got3.view(np.uint32), want.view(np.uint32)) and np.array_equal(gprim3, wprim)
+        # a later pass that covers only SOME tiles, and a resolve right after rt_continue_frame: what the other devices rendered
+        # in the earlier pass must still come home (the gather lists the tiles of the frame, not those of the last pass)
+        subset = rt.interleaved_tiles(100, 72)[1::2]
+        frames = []
+        for c_ in (multi, ctx):
+            c_.set_camera(cam)
+            c_.begin_frame(p1)
+            for t in rt.interleaved_tiles(100, 72):
+                c_.render_tile(*t)
+            c_.continue_frame(1)
+            a_rgb, a_prim, _ = c_.download()          # nothing queued in the new pass yet
+            for t in subset:
+                c_.render_tile(*t)
+            b_rgb, b_prim, _ = c_.download()
+            frames.append((a_rgb.copy(), a_prim.copy(), b_rgb.copy(), b_prim.copy()))
+        for g, w_ in zip(frames[0], frames[1]):
+            assert np.array_equal(g.view(np.uint32), w_.view(np.uint32))
+        assert (frames[0][1][..., 0] != 0xFFFFFFFF).any() and np.isfinite(frames[0][0]).all() and frames[0][0].max() > 0
         # the seams on explicit rays run on the first device
         org, dirs = multi.camera_rays(p, 10, 10, 8, 8)
         assert np.array_equal(multi.intersect(org, dirs), ctx.intersect(org, dirs))

@@ -31,6 +31,31 @@ def test_static_trace_equals_rt_trace_twice(rt, ctx, scene):
         assert np.isfinite(want).all() and float(np.abs(want).max()) > 0.0
 
 
+def test_static_trace_leaves_free_device_memory_unchanged(rt, ctx):
+    """The property the entry point exists for: a (warm) call allocates and frees nothing on the device. hipMemGetInfo is read
+    through the HIP runtime the library is bound to (by soname, as tests/test_progressive.py does); rt_trace, which stages
+    its inputs in buffers of its own, serves as the check that the probe sees an allocation when there is one."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    ctx.upload_scene(rt.HostScene("mesh_gorilla", 3, 12))
+    p, org, dirs, pixel, sample = _rays(rt, ctx, 64, 32, 2, 5)
+    want = ctx.trace(org, dirs, p, pixel, sample)
+    ctx.trace(org, dirs, p, pixel, sample, static=True)             # warm: code objects loaded, scratch address taken
+    before = free_bytes()
+    got = ctx.trace(org, dirs, p, pixel, sample, static=True)
+    p2, org2, dirs2, pixel2, sample2 = _rays(rt, ctx, 24, 20, 3, 9)
+    ctx.trace(org2, dirs2, p2, pixel2, sample2, static=True)
+    assert free_bytes() == before, "rt_trace_static changed the free device memory"
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_static_trace_refuses_what_it_cannot_hold(rt, ctx):
     ctx.upload_scene(rt.HostScene("refraction", 3, 12))
     p, org, dirs, pixel, sample = _rays(rt, ctx, 80, 52, 1, 1)          # 4160 rays > 4096
