@@ -45,6 +45,7 @@ L2_PEAK_GBS = 34500.0          # ... aggregate L2 bandwidth
 # measures 66 T for v_add_u32, 53 T for v_fma_f32 and 35-38 T for the min/max/perm/cvt/cmp/select class (4 cycles per
 # instruction) that most of k_shadow consists of: VALU_SLOW_CLASS is that second rate, reported beside the peak.
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+VALU_PEAK_TFLOPS = 2.0 * VALU_PEAK_TLANEOPS       # 157.3 TFLOP/s f32 vector (an fma is two flops), MI355X_MICROARCH.md
 VALU_SLOW_CLASS_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # Vector L1: one lane-access (one lane x one load instruction) per clock per CU for divergent loads, measured
 # (tools/micro/l1_rate.hip, profiles/r02_micro_l1_rate.txt: 0.99 whatever the table size and the width of the load).
@@ -67,6 +68,18 @@ def algorithmic_bytes_per_ray(n_node, n_tri):
     return n_node * 64.0 + n_tri * 48.0 + 32.0 + 16.0
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources the library is built from; tools/pmc_c5_json.py stamps the PMC file with the same."""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for f in ("ray-tracing_amd/csrc/rt_kernels.h", "ray-tracing_amd/csrc/rt_device.h", "ray-tracing_amd/csrc/rtgpu.hip"):
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+    except OSError:
+        return None
+    return h.hexdigest()
+
+
 def load_json(path):
     try:
         with open(path) as f:
@@ -85,12 +98,11 @@ def time_side_config(rt, torch, device, name):
         ctx.set_camera(rt.default_camera(W / H))
         params = rt.make_params(W, H, spp=spp, max_depth=depth, light_samples=35, shadow_mode=0, jitter=1, seed=0)
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device=f"cuda:{device}")
-        tiles = rt.interleaved_tiles(W, H)
+        tiles = np.asarray(rt.interleaved_tiles(W, H), np.int32)
 
         def step():
             ctx.begin_frame(params)
-            for t in tiles:
-                ctx.render_tile(*t)
+            ctx.render_tiles(tiles)                    # the per-pixel tasks of main.cpp:210-225, queued with one call
             ctx.resolve_device(frame.data_ptr())
             return ctx.stats()
 
@@ -165,10 +177,11 @@ def main():
     gather = rtd.FrameGather(W, H, world, dev, 32)
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
 
+    tiles = np.asarray(tiles, np.int32).reshape(-1, 4)
+
     def step():
         ctx.begin_frame(params)
-        for t in tiles:
-            ctx.render_tile(*t)
+        ctx.render_tiles(tiles)                    # this rank's tiles, queued with one call
         ctx.resolve_device(frame.data_ptr())       # runs the queued tiles, writes this rank's pixels
         gather(frame, rank)                        # RCCL all-gather of the packed tile slabs + scatter
         return ctx.stats()
@@ -256,13 +269,25 @@ def main():
             roof = {"kernel": "k_shadow", "avg_launch_ms": round(avg_s * 1e3, 3), "launches": n_shadow, "rays_per_launch": round(rays_per_launch, 1),
                     "closest_kernel_ms": round(ms_closest / max(n_closest, 1), 3)}
             if pmc:
+                # the per-ray counters come from a committed PMC run (tools/pmc_c5.sh): they describe THIS build only if the kernel
+                # sources have not changed since -- otherwise no fraction is quoted
+                fresh = pmc.get("kernel_source_sha256") is not None and pmc.get("kernel_source_sha256") == kernel_source_hash()
+                roof["pmc_matches_build"] = bool(fresh)
+            if pmc and not roof["pmc_matches_build"]:
+                roof.update({"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TLANEOPS, 3), "unit": "Tlane-op/s", "frac": None, "traffic": None,
+                             "note": "profiles/c5_k_shadow_pmc.json was taken on other kernel sources: rerun tools/pmc_c5.sh + tools/pmc_c5_json.py"})
+            elif pmc:
                 ops_per_ray = pmc["SQ_THREAD_CYCLES_VALU_per_launch"] / pmc["rays_per_launch"]
                 achieved = ops_per_ray * rays_per_launch / avg_s / 1e12
+                # SURVEY 8(d)'s flop formula on the steps the kernel actually executed (RT_COUNT of the PMC run): 4 boxes per 4-wide node step
+                flops_per_ray = pmc["node_steps_per_ray"] * 4.0 * 30.0 + pmc["tri_steps_per_ray"] * 160.0
                 hbm_bytes = (2.0 * pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024.0 / pmc["rays_per_launch"] * rays_per_launch
                 ex_bpr = pmc["node_steps_per_ray"] * 64.0 + pmc["tri_steps_per_ray"] * 128.0 + 32.0
                 roof.update({
                     "bound": "valu", "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 3), "unit": "Tlane-op/s",
                     "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": round(hbm_bytes),
+                    "flop_frac": round(flops_per_ray * rays_per_launch / avg_s / 1e12 / VALU_PEAK_TFLOPS, 4),
+                    "flops_per_ray_8d_formula_executed_steps": round(flops_per_ray, 1),
                     "valu_lane_ops_per_ray": round(ops_per_ray, 1),
                     "lanes_active_per_valu_inst": round(pmc["SQ_THREAD_CYCLES_VALU_per_launch"] / (64.0 * pmc["SQ_INSTS_VALU_per_launch"]), 4),
                     "valu_insts_per_ray": round(pmc["SQ_INSTS_VALU_per_launch"] / pmc["rays_per_launch"], 1),

@@ -190,6 +190,10 @@ int rt_continue_frame(rt_ctx*, int32_t more_spp);
 /* Queues the pixels [x0,x0+w) x [y0,y0+h) (the per-pixel ThreadPool tasks of main.cpp:210-225).
  * Asynchronous: the work runs at the next rt_download_framebuffer / rt_resolve_device / rt_flush. */
 int rt_render_tile(rt_ctx*, int x0, int y0, int w, int h);
+/* The same for n tiles at once, xywh = n x (x0, y0, w, h): the enqueue loop of main.cpp:210-225 in one call (a 4K frame is
+ * 8160 tiles of 32 x 32; through a foreign-function interface that is 8160 calls otherwise). Stops at the first tile that is
+ * refused; the tiles before it stay queued. */
+int rt_render_tiles(rt_ctx*, const int32_t* xywh, int64_t n);
 /* Runs all queued tiles to completion on the device.
  * Queue capacities: a batch of B path states can append at most 2 B children (two per glass hit) and B diffuse records,
  * which is what the queues hold, and the path-state stack holds batch x (max_depth + 3): by construction they cannot

@@ -116,7 +116,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
 
 # every symbol include/rtgpu.h and include/rthost.h declare
 EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame", "rt_continue_frame",
-           "rt_render_tile", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_resolve_rgba8_device", "rt_get_stats",
+           "rt_render_tile", "rt_render_tiles", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_resolve_rgba8_device", "rt_get_stats",
            "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion", "rt_filter_passes",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
            "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_build_mode", "rth_scene_desc",
@@ -150,6 +150,7 @@ def lib():
     L.rt_begin_frame.argtypes = [vp, C.POINTER(RenderParams)]
     L.rt_continue_frame.argtypes = [vp, i32]
     L.rt_render_tile.argtypes = [vp, i32, i32, i32, i32]
+    L.rt_render_tiles.argtypes = [vp, vp, i64]
     L.rt_flush.argtypes = [vp]
     L.rt_download_framebuffer.argtypes = [vp, vp, vp, C.POINTER(Stats)]
     L.rt_resolve_device.argtypes = [vp, vp]
@@ -404,6 +405,11 @@ class Context:
     def render_tile(self, x0, y0, w, h):
         self._check(self.L.rt_render_tile(self.h, x0, y0, w, h), "rt_render_tile")
 
+    def render_tiles(self, tiles):
+        """Queues many tiles with one call; tiles: sequence of (x0, y0, w, h) or an int32 array of shape (n, 4)."""
+        a = np.ascontiguousarray(tiles, np.int32).reshape(-1, 4)
+        self._check(self.L.rt_render_tiles(self.h, _ptr(a), len(a)), "rt_render_tiles")
+
     def flush(self):
         self._check(self.L.rt_flush(self.h), "rt_flush")
 
@@ -433,8 +439,7 @@ class Context:
         self.begin_frame(params)
         if tiles is None:
             tiles = interleaved_tiles(params.img_w, params.img_h)
-        for t in tiles:
-            self.render_tile(*t)
+        self.render_tiles(tiles)
         return self.download()
 
     def intersect(self, org, dirs):

@@ -2069,6 +2069,15 @@ int rt_render_tile(rt_ctx* c, int x0, int y0, int w, int h) {
     return RT_OK;
 }
 
+int rt_render_tiles(rt_ctx* c, const int32_t* xywh, int64_t n) {
+    if (!c || (n > 0 && !xywh) || n < 0) return RT_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        const int rc = rt_render_tile(c, xywh[4 * i], xywh[4 * i + 1], xywh[4 * i + 2], xywh[4 * i + 3]);
+        if (rc) return rc;
+    }
+    return RT_OK;
+}
+
 int rt_flush(rt_ctx* c) {
     if (!c) return RT_ERR_ARG;
     if (!c->subs.empty()) {

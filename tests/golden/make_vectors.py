@@ -27,6 +27,10 @@ OUT = os.path.join(HERE, "vectors")
 CONFIGS = {
     "C1_final_default_pose": dict(scene="final", mesh_depth=12, w=480, h=480, crop=40, zoom=3.0, max_depth=50),
     "C1_final_pulled_back": dict(scene="final", mesh_depth=12, w=480, h=480, crop=40, zoom=25.0, max_depth=6),
+    # glass meshes in direct view at the reference's own depth (Scene.h:283-286): what contribution culling and the LIFO stack are
+    # held against. Minutes of oracle time (the depth-50 recursion inside the glass flamingos), so only the GPU test loads it.
+    # ("window": the crop x crop grid of rays and the rendered crop sit on the glass gorilla's place in the frame, pixels 90-180 x 165-285)
+    "C1_final_pulled_back_d50": dict(scene="final", mesh_depth=12, w=480, h=480, crop=12, zoom=25.0, max_depth=50, window=[90, 165, 90, 120]),
     "C3_refraction_1080p": dict(scene="refraction", mesh_depth=12, w=1920, h=1080, crop=64, zoom=3.0, max_depth=5),
     "C4_mesh_gorilla_1080p": dict(scene="mesh_gorilla", mesh_depth=12, w=1920, h=1080, crop=64, zoom=3.0, max_depth=50),
     "C4_mesh_cow_1080p": dict(scene="mesh_cow", mesh_depth=12, w=1920, h=1080, crop=64, zoom=3.0, max_depth=50),
@@ -44,10 +48,11 @@ def vector_inputs(cfg):
     the render entry point is run on."""
     w, h, c = cfg["w"], cfg["h"], cfg["crop"]
     cam = O.default_camera(w / h, zoom=cfg["zoom"])
-    x0, y0 = (w - c) // 2, (h - c) // 2
+    wx, wy, ww, wh = cfg.get("window", [0, 0, w, h])
+    x0, y0 = wx + (ww - c) // 2, wy + (wh - c) // 2
     p1 = O.make_params(w, h, spp=1, max_depth=cfg["max_depth"], light_samples=35, shadow_mode=1, jitter=0, seed=11)
-    xs = ((np.arange(c) * 2 + 1) * w) // (2 * c)
-    ys = ((np.arange(c) * 2 + 1) * h) // (2 * c)
+    xs = wx + ((np.arange(c) * 2 + 1) * ww) // (2 * c)
+    ys = wy + ((np.arange(c) * 2 + 1) * wh) // (2 * c)
     org, dirs = [], []
     for y in ys:
         o, d = O.camera_rays(cam, p1, 0, int(y), w, 1)
@@ -56,6 +61,20 @@ def vector_inputs(cfg):
     org, dirs = np.concatenate(org), np.concatenate(dirs)
     pixel = (xs[None, :] + ys[:, None] * w).reshape(-1).astype(np.uint32)
     return cam, x0, y0, org, dirs, pixel
+
+
+def trace_parallel(sc, org, dirs, p, pixel, workers=8):
+    """Scene::rayTrace per ray, the rays dealt to a few threads (every ray is on its own: same bits as one call)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(org)
+    if n < 2 * workers:
+        return sc.trace(org, dirs, p, pixel)
+    out = np.zeros((n, 3), np.float32)
+    parts = [np.arange(k, n, workers) for k in range(workers)]
+    with ThreadPoolExecutor(workers) as ex:
+        for idx, rgb in zip(parts, ex.map(lambda idx: sc.trace(org[idx], dirs[idx], p, pixel[idx]), parts)):
+            out[idx] = rgb
+    return out
 
 
 def tree_stats(sc, which):
@@ -74,7 +93,8 @@ def make(name, cfg):
         out["hit_" + f + "_bits"] = np.ascontiguousarray(hits[f]).view(np.uint32)
     for mode, tag in ((1, "hard"), (0, "soft")):
         p = O.make_params(cfg["w"], cfg["h"], spp=1, max_depth=cfg["max_depth"], light_samples=35, shadow_mode=mode, jitter=0, seed=11)
-        out["rgb_" + tag + "_bits"] = sc.trace(org, dirs, p, pixel).view(np.uint32)
+        out["rgb_" + tag + "_bits"] = trace_parallel(sc, org, dirs, p, pixel).view(np.uint32)
+        print(name, tag, "traced", flush=True)
     # ray counts of the same crop through the render entry point (pixel centres, hard shadows)
     p = O.make_params(cfg["w"], cfg["h"], spp=1, max_depth=cfg["max_depth"], light_samples=35, shadow_mode=1, jitter=0, seed=11)
     rgb, prim, st, _ = sc.render(cam, p, x0, y0, cfg["crop"], cfg["crop"], threads=8)

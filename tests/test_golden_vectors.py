@@ -17,7 +17,9 @@ spec = importlib.util.spec_from_file_location("make_vectors", os.path.join(HERE,
 MV = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(MV)
 
-CPU_CONFIGS = [n for n in MV.CONFIGS if n != "C5_soup_10M_4k"]      # the 10 M-triangle oracle is for the GPU box
+GPU_ONLY = ("C5_soup_10M_4k",                  # the 10 M-triangle oracle is for the GPU box
+            "C1_final_pulled_back_d50")        # minutes of depth-50 glass recursion on the CPU
+CPU_CONFIGS = [n for n in MV.CONFIGS if n not in GPU_ONLY]
 
 
 def load(name):
@@ -63,7 +65,7 @@ def test_vector_files_are_complete():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(MV.CONFIGS))
-def test_hip_path_meets_the_frozen_vectors(rt, ctx, name):
+def test_hip_path_meets_the_frozen_vectors(rt, ctx, name, monkeypatch):
     d, cfg = load(name)
     hs = rt.HostScene(cfg["scene"], 3, cfg["mesh_depth"])
     ctx.upload_scene(hs)
@@ -83,9 +85,27 @@ def test_hip_path_meets_the_frozen_vectors(rt, ctx, name):
     want_prim = d["render_prim"].astype(np.int64)
     want_prim[d["render_prim"][..., 0] < 0] = 0xFFFFFFFF
     assert np.array_equal(prim[y0:y0 + c, x0:x0 + c].astype(np.int64), want_prim)
-    assert [st.rays_primary, st.rays_secondary, st.rays_shadow] == d["rays"].tolist()
     dq = np.abs(O.quantize(rgb[y0:y0 + c, x0:x0 + c]) - O.quantize(d["render_rgb_bits"].view(np.float32)))
     assert dq.max() <= 1
+    if name == "C1_final_pulled_back_d50":
+        # Depth 50 below glass and mirrors seen directly: the frame above was rendered WITH contribution culling (the default)
+        # and met the oracle's radiance, which traces everything; its ray counts are lower than the reference's by what was
+        # culled. With RT_NO_CULL the library follows every path as Scene.h:230-272 does: counts equal the oracle's, bits equal
+        # the culled frame's.
+        assert st.rays_primary == d["rays"][0] and 0 < st.rays_secondary < d["rays"][1] and st.shadow_queries <= d["rays"][2]
+        monkeypatch.setenv("RT_NO_CULL", "1")
+        full = rt.Context(0)
+        try:
+            full.upload_scene(hs)
+            frgb, fprim, fst = full.render(cam, params(rt, cfg, 1), tiles=[(x0, y0, c, c)])
+        finally:
+            full.close()
+            monkeypatch.delenv("RT_NO_CULL")
+        assert [fst.rays_primary, fst.rays_secondary, fst.rays_shadow] == d["rays"].tolist() and fst.rays_shadow_culled == 0
+        assert np.array_equal(frgb.view(np.uint32), rgb.view(np.uint32)) and np.array_equal(fprim, prim)
+        assert d["rays"][1] > 1000 * d["rays"][0]            # (the vector is what it is meant to be: a deep recursion)
+    else:
+        assert [st.rays_primary, st.rays_secondary, st.rays_shadow] == d["rays"].tolist()
     # the trees the host mirror built are the frozen ones
     a = hs.arrays()
     assert [len(a["top_nodes"]) + len(a["top_leaves"]), len(a["top_leaves"])] == d["tree_top"].tolist()[:2]

@@ -53,11 +53,11 @@ def main():
     params = rt.make_params(W, H, spp=spp, max_depth=depth, light_samples=35, shadow_mode=0, jitter=1, seed=0)
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
 
+    tiles = [(x, y, min(32, W - x), min(32, H - y)) for y in range(0, H, 32) for x in range(0, W, 32)]
+
     def step():
         ctx.begin_frame(params)
-        for y in range(0, H, 32):
-            for x in range(0, W, 32):
-                ctx.render_tile(x, y, min(32, W - x), min(32, H - y))
+        ctx.render_tiles(tiles)
         ctx.resolve_device(frame.data_ptr())
         return ctx.stats()
 

@@ -26,6 +26,12 @@ rec = {"rays_per_launch": rays / launches, "launches": launches, "waves_per_simd
        "source": f"profiles/{tag}_pmc_c5.txt (tools/pmc_c5.sh: rocprofv3 --pmc passes over one full frame, `bench.py --steps 1 --warmup 0 --no-cpu --no-side`; "
                  "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md)"}
 rec.update(per)
+# the kernels these counters were taken on: bench.py recomputes this hash and refuses to price a newer build with old counters
+import hashlib
+h = hashlib.sha256()
+for f in ("ray-tracing_amd/csrc/rt_kernels.h", "ray-tracing_amd/csrc/rt_device.h", "ray-tracing_amd/csrc/rtgpu.hip"):
+    h.update(open(os.path.join(ROOT, f), "rb").read())
+rec["kernel_source_sha256"] = h.hexdigest()
 path = os.path.join(ROOT, "profiles", "c5_k_shadow_pmc.json")
 allrec = json.load(open(path)) if os.path.exists(path) else {}
 allrec[key] = rec
