@@ -116,11 +116,17 @@ struct DScene {
      * byte offsets of tnodes, tleaves, titems, squares, spheres, meshes inside top_blob */
     const float4* top_blob;
     int32_t top_blob_bytes;
-    int32_t top_off[7];         /* ... and tsub: per top-level leaf the root of the sub-tree over its objects, or LINK_NONE */
+    int32_t top_off[8];         /* ... and tsub: per top-level leaf the root of the sub-tree over its objects, or LINK_NONE; [7]: the flat leaf table (n_flat) */
+    int32_t n_flat;             /* k_shadow with the flat top-level pass: number of top-level leaves with a box, in the order the reference's walk meets them
+                                 * (2 x float4 each: box min.xyz max.x | max.yz, leaf index, -); 0 = no flat pass (rtgpu.hip) */
     int32_t has_topsub;         /* some top-level leaves carry a sub-tree over their objects (rtgpu.hip) */
     float light_sum;            /* sum over the lights of their largest colour component; < 0: contribution culling off (k_closest) */
     const float* cull_gpow;     /* [RT_MAX_PATH_DEPTH + 2]: entry r bounds how much a path's throughput can grow over r more bounces (k_closest) */
     float cull_cmax;            /* what one hit (or the sky) can add per unit of throughput, any material of the scene; < 0: no culling of path states */
+    /* per launch (run_wavefront): k_closest leaves, in a diffuse record's code slot, the state of the counter RNG after the rounds its shadow
+     * rays share (rt_rng_prefix) instead of the path code, so that no pass over the records (k_hash_records) is needed for it */
+    int32_t rng_hash;
+    uint32_t rng_seed;
 };
 /* head of section 6 of top_blob, in front of tsub */
 struct TopFrame {

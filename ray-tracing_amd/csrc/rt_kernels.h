@@ -993,7 +993,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
         q[1] = make_float4(rec.N[1], rec.N[2], rec.V[0], rec.V[1]);
         q[2] = make_float4(rec.V[2], rec.thr[0], rec.thr[1], rec.thr[2]);
         q[3] = make_float4(__uint_as_float(rec.mat), __uint_as_float(rec.slot), __uint_as_float(rec.pixel), __uint_as_float(rec.sample));
-        dcode[dbase] = code;
+        dcode[dbase] = sc.rng_hash ? (unsigned long long)rt_rng_prefix(sc.rng_seed, rec.pixel, rec.sample, code) : code;
         dtex[dbase] = rec_rgb;
     }
 }
@@ -1079,6 +1079,10 @@ RT_DEV void shadow_restart(const DScene& sc, ShadowLane& s, int mode, int limit)
     s.ts = (uint32_t)mode | ((uint32_t)limit << 20);
     if (mode == 1) s.bound = 3.4028233e38f;             /* (mode 0: the refill has put lightDistance there) */
     s.tlink = sc.top_root; s.top_pos = s.top_end = 0;
+    if (sc.n_flat > 0) {                                /* flat top-level pass (k_shadow<5> only: the host zeroes n_flat for the others): the ray's leaf mask, kept in entry 0 of the lane's LDS stack */
+        extern __shared__ __align__(16) int s_stack[];
+        s.tlink = s_stack[threadIdx.x];
+    }
     s.tri_pos = TRI_NONE;                               /* (at the top level this word only ever holds an object handed over by a leaf's sub-tree) */
     s.st = ST_TOP;
 }
@@ -1094,7 +1098,7 @@ RT_DEV void shadow_on_hit(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
     shadow_restart(sc, s, 1, visited);
 }
 /* the top-level tables as k_shadow reads them: in global memory, or its LDS copy (generic pointers) */
-struct TopTables { const float4* tnodes; const uint2* tleaves; const uint32_t* titems; const float4* squares; const float4* spheres; const DMesh* meshes; const TopFrame* tf; const int* tsub; };
+struct TopTables { const float4* tnodes; const uint2* tleaves; const uint32_t* titems; const float4* squares; const float4* spheres; const DMesh* meshes; const TopFrame* tf; const int* tsub; const float4* flat; };
 #define RT_TOP_LDS_MAX 2048
 struct WideStack { int* lds; int* ovf; int lds_cap; const TopFrame* tf; };
 RT_DEV void wpush(const WideStack& w, int& sp, int link);
@@ -1148,6 +1152,63 @@ RT_DEV bool shadow_top_item(const DScene& sc, const TopTables& tt, ShadowLane& s
     return true;
 }
 /* top-level state machine: runs until the ray ends or enters a mesh tree (or, TOPSUB, the sub-tree of a top-level leaf) */
+/* Flat top-level pass (k_shadow<5>). The reference walks its top-level tree left first and enters every child whose box passes
+ * AABB::intersect (AccelerationStruct.cpp:315-336); its boxes are nested, so a leaf is reached iff its OWN box passes (monotone slab
+ * arithmetic, the argument of the quantised mesh trees), and the leaves are met in the tree's left-to-right order. For a tree of at
+ * most 32 leaves the walk is therefore a bit mask: flat_reach() runs the reference's slab test on every leaf's own box when the ray
+ * is taken on -- all refilled lanes together, outside the divergent loop -- and the top-level state machine then only takes the next
+ * set bit: no node steps, no stack. Mode 1 ("does an earlier leaf hold any hit at all") walks the same mask again up to its limit. */
+RT_DEV uint32_t flat_reach(const TopTables& tt, int n_flat, const Ray& r) {
+    uint32_t mask = 0u;
+#pragma unroll 1
+    for (int i = 0; i < n_flat; i++) {
+        const float4 a = tt.flat[2 * i], b = tt.flat[2 * i + 1];
+        float tEnter;
+        if (slab(r, a.x, a.y, a.z, a.w, b.x, b.y, tEnter)) mask |= 1u << i;
+    }
+    return mask;
+}
+template <bool QUANT>
+RT_DEV void shadow_advance_top_flat(const DScene& sc, const TopTables& tt, ShadowLane& s, uint32_t* cnt, const WideStack& w) {
+    if (s.tri_pos != TRI_NONE) {
+        /* the walk of a leaf's sub-tree has reached an object (shadow_quant_step); afterwards that walk goes on */
+        const int ord = (int)(s.tri_pos & ~TOP_ITEM);
+        s.tri_pos = TRI_NONE;
+        if (shadow_top_item<QUANT, true>(sc, tt, s, ord, w, cnt)) return;
+        s.link = LINK_NONE;
+        s.st = ST_MESH;
+        return;
+    }
+    for (;;) {
+        if (s.top_pos < s.top_end) {
+            int ord = (int)tt.titems[s.top_pos++];
+            if (shadow_top_item<QUANT, false>(sc, tt, s, ord, w, cnt)) return;
+            continue;
+        }
+        if (s.ts & TS_OPEN) s.ts = (s.ts & ~TS_OPEN) + TS_VISITED_ONE;
+        const uint32_t mask = (uint32_t)s.tlink;
+        if (mask == 0u) { shadow_finish(s, (s.ts & TS_MODE) != 0u, cnt); return; }     /* mode 0: no occluder; mode 1: nothing hides it */
+        if ((s.ts & TS_MODE) && TS_VISITED(s.ts) >= TS_LIMIT(s.ts)) { shadow_finish(s, true, cnt); return; }
+        const int bit = __builtin_ctz(mask);
+        s.tlink = (int)(mask & (mask - 1u));
+        const int leaf = __float_as_int(tt.flat[2 * bit + 1].z);
+        s.ts |= TS_OPEN;
+        const int sub = tt.tsub[leaf];
+        const TopFrame* tf = tt.tf;
+        const bool inside = s.r.o.x >= tf->omin[0] && s.r.o.x <= tf->omax[0] && s.r.o.y >= tf->omin[1] && s.r.o.y <= tf->omax[1] &&
+                            s.r.o.z >= tf->omin[2] && s.r.o.z <= tf->omax[2];
+        if (sub != LINK_NONE && inside) {
+            s.top_pos = s.top_end = 0;
+            s.prune_raw = (s.ts & TS_MODE) == 0u ? s.bound * 1.00002f : INFINITY;
+            quant_setup(s.q, s.r, tf->frame);
+            s.link = sub; s.msp = sc.top_cap; s.tri_pos = TRI_NONE;
+            s.st = ST_MESH;
+            return;
+        }
+        uint2 lf = tt.tleaves[leaf];
+        s.top_pos = lf.x; s.top_end = lf.x + lf.y;
+    }
+}
 template <bool QUANT, bool TOPSUB>
 RT_DEV void shadow_advance_top(const DScene& sc, const TopTables& tt, ShadowLane& s, int* stk, int stride, uint32_t* cnt, const WideStack& w) {
     if (TOPSUB && s.tri_pos != TRI_NONE) {
@@ -1595,13 +1656,13 @@ __global__ void __launch_bounds__(RT_FBLOCK) k_shadow_front(DScene sc, FrameD fr
 
 /* Work is phased so that the lanes of a wave execute the same kind of step together: a node phase
  * (lanes with a pending triangle wait) and a triangle phase (postponed tests run side by side). */
-template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves and batched top-level rounds, 3: ... and sub-trees over the objects of top-level leaves. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
+template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves and batched top-level rounds, 3: ... and sub-trees over the objects of top-level leaves, 5: mode 3 with the flat top-level pass. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
                                                         uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds,
                                                         int* ovf, int lds_cap, int ovf_cap, int top_min, const unsigned long long* total_ptr) {
     constexpr bool count_steps = COUNT;
     if (total_ptr) total = *total_ptr;       /* the rays the front pass deferred (k_shadow_front) */
-    constexpr bool QUANT = MODE != 0, SUB = MODE >= 2, TOPSUB = MODE == 3;
+    constexpr bool QUANT = MODE != 0, SUB = MODE >= 2, TOPSUB = MODE == 3 || MODE == 5, FLAT = MODE == 5;
     /* the plane filter in front of the triangle test pays where triangle rounds are a large part of a short walk (the
      * default scene: 14 node and 5 triangle steps per ray, -10 %); on the soup, where a ray takes 13 node steps per
      * triangle, the lanes that wait with a candidate thin out the node rounds (+2 %), and the single-mesh scenes are
@@ -1633,6 +1694,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         tt.meshes = reinterpret_cast<const DMesh*>(base + sc.top_off[5]);
         tt.tf = reinterpret_cast<const TopFrame*>(base + sc.top_off[6]);
         tt.tsub = reinterpret_cast<const int*>(base + sc.top_off[6] + sizeof(TopFrame));
+        tt.flat = reinterpret_cast<const float4*>(base + sc.top_off[7]);
         wst.tf = tt.tf;
     }
     ShadowLane s;
@@ -1678,6 +1740,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
                 s.r.d = f3(rd.x, rd.y, rd.z);
                 s.r.inv = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);                 /* AccelerationStruct.cpp:19 */
                 s.tri_pos = TRI_NONE;
+                if (FLAT) stk[0] = (int)flat_reach(tt, sc.n_flat, s.r);        /* (before the restart, which reads it back) */
                 shadow_restart(sc, s, 0, 0);
             }
         }
@@ -1694,7 +1757,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const int ntop = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_TOP));
             top_round = ntop >= top_min || __builtin_amdgcn_ballot_w64(s.st >= ST_MESH) == 0ull;
         }
-        if (top_round && s.st == ST_TOP) shadow_advance_top<QUANT, TOPSUB>(sc, tt, s, stk, stride, cnt, wst);
+        if (top_round && s.st == ST_TOP) { if (FLAT) shadow_advance_top_flat<QUANT>(sc, tt, s, cnt, wst); else shadow_advance_top<QUANT, TOPSUB>(sc, tt, s, stk, stride, cnt, wst); }
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_top += k_t1 - k_t0; k_t0 = k_t1; }
         /* node phase */
 #pragma unroll 1

@@ -357,6 +357,8 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
          * the same lines, and the binary walk over the reference's nodes is the faster one (C5, 32 Mi primaries: 37 ms against
          * 53). Both return the same hit, bit for bit. */
         DScene scl = c->sc;
+        const bool fuse_hash = c->fr.shadow_mode == 0 && L > 0 && !getenv("RT_SEPARATE_HASH");      /* (test knob: the separate pass must leave the same bits) */
+        scl.rng_hash = fuse_hash ? 1 : 0; scl.rng_seed = c->fr.seed;
         scl.wide_closest = (c->sc.wide_closest && (c->wide_mode == 1 || (c->wide_mode == 2 && 2ull * n_new < nb))) ? 1 : 0;
         const bool wide = scl.wide_closest != 0;
         if (wide && cblock > 64u && lds_bytes_closest(c, cblock, true) + 64 > c->lds_max) cblock = 64u;
@@ -399,7 +401,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         if (n_diff && L > 0) {
             HIP_TRY(c, hipMemsetAsync(w.cnt, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
             const unsigned long long per_rec = (unsigned long long)L * S;
-            if (c->fr.shadow_mode == 0)
+            if (c->fr.shadow_mode == 0 && !fuse_hash)
                 hipLaunchKernelGGL(k_hash_records, dim3((n_diff + 255) / 256), dim3(256), 0, c->stream, c->fr.seed, w.drec, w.dcode, n_diff);
             /* no meshes: one thread per ray from record to verdict (k_shadow_direct), no ray buffer, no persistent kernel */
             const bool direct = c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW");
@@ -471,13 +473,17 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                 int top_min = c->sc.n_top_items >= 24 ? 32 : 1;       /* see k_shadow; measured on the default scene: 1, 8, 16, 32, 48, 60 -> 2365, 2205, 2065, 1828, 1839, 2111 ms */
                 if (c->sc.has_topsub) top_min = 1;                     /* (with sub-trees over the objects a top-level round is short: 32 / 16 / 8 / 1 -> 94.7 / 93.1 / 92.6 / 91.9 ms on the default scene at 4 spp) */
                 if (const char* e = getenv("RT_TOP_MIN")) top_min = std::max(1, atoi(e));
+                const bool flat_top = c->sc.quant_ok && c->sc.has_topsub && c->sc.n_flat > 0;      /* k_shadow<5>: the variant of mode 3 with the flat top-level pass (forced onto the scenes of mode 2 it loses: chamber 122 -> 137 ms, gorilla 42.3 -> 45.2, cow 29.1 -> 31.8 -- they pay for mode 3's plane filter and object sub-trees, and have two to four top-level leaves) */
+                DScene scs = c->sc;
+                if (!flat_top) scs.n_flat = 0;
                 auto launch = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks_now), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, c->sc,
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks_now), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, scs,
                                        static_cast<const float4*>(w.srays), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds,
                                        w.ovf, lds_cap, ovf_cap, top_min,
                                        front ? static_cast<const unsigned long long*>(&d_ctr->deferred) : static_cast<const unsigned long long*>(nullptr));
                 };
-                if (c->sc.quant_ok && c->sc.has_topsub) { if (c->count_steps) launch(k_shadow<3, true>); else launch(k_shadow<3, false>); }
+                if (flat_top) { if (c->count_steps) launch(k_shadow<5, true>); else launch(k_shadow<5, false>); }
+                else if (c->sc.quant_ok && c->sc.has_topsub) { if (c->count_steps) launch(k_shadow<3, true>); else launch(k_shadow<3, false>); }
                 else if (c->sc.quant_ok && (c->sc.has_sub || top_min > 1)) { if (c->count_steps) launch(k_shadow<2, true>); else launch(k_shadow<2, false>); }
                 else if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<1, true>); else launch(k_shadow<1, false>); }
                 else { if (c->count_steps) launch(k_shadow<0, true>); else launch(k_shadow<0, false>); }
@@ -1793,6 +1799,47 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
             memcpy(sec.data(), &tf, sizeof(TopFrame));
             memcpy(sec.data() + sizeof(TopFrame), tsub.data(), tsub.size() * sizeof(int32_t));
             section(sec.data(), sec.size(), 6);
+        }
+        {   /* The flat top-level pass of k_shadow (rt_kernels.h, "flat top-level pass"): the top-level leaves with their own boxes in
+             * the order the reference's left-first walk meets them (AccelerationStruct.cpp:315-336). Usable when the tree has an inner
+             * root, at most 32 leaves, and finite boxes that are nested (a child's two boxes inside the box its parent has for it):
+             * then "the leaf's own box passes AABB::intersect => every box above it passes" (monotone slab arithmetic, as for the
+             * mesh trees), the reference reaches exactly the leaves whose own box passes, in this order. */
+            std::vector<float4> flat;
+            bool ok = !getenv("RT_NO_FLAT_TOP") && d->top_root >= 0 && d->n_top_leaves <= 32 && (d->n_squares + d->n_spheres + d->n_meshes) > 0;
+            std::function<void(int32_t)> walk = [&](int32_t node) {
+                const rt_bvh_node& n = tnodes[(size_t)node];
+                const float* bmin[2] = {n.lmin, n.rmin};
+                const float* bmax[2] = {n.lmax, n.rmax};
+                const int32_t link[2] = {n.left, n.right};
+                for (int sd = 0; sd < 2 && ok; sd++) {
+                    const bool empty = !(bmin[sd][0] <= bmax[sd][0]) || !(bmin[sd][1] <= bmax[sd][1]) || !(bmin[sd][2] <= bmax[sd][2]);
+                    if (!empty) for (int k = 0; k < 3; k++) if (!(std::fabs(bmin[sd][k]) < 1e30f) || !(std::fabs(bmax[sd][k]) < 1e30f)) ok = false;
+                    if (link[sd] >= 0) {
+                        if (empty) { ok = false; continue; }       /* (an inner node under an empty box: not a tree of bounding boxes) */
+                        const rt_bvh_node& ch = tnodes[(size_t)link[sd]];
+                        const float* cmn[2] = {ch.lmin, ch.rmin};
+                        const float* cmx[2] = {ch.lmax, ch.rmax};
+                        for (int t = 0; t < 2; t++) {
+                            if (!(cmn[t][0] <= cmx[t][0])) continue;             /* an empty child box (inverted, +-inf) misses anyway */
+                            for (int k = 0; k < 3; k++) if (!(cmn[t][k] >= bmin[sd][k]) || !(cmx[t][k] <= bmax[sd][k])) ok = false;
+                        }
+                        walk(link[sd]);
+                    } else if (!empty) {
+                        const int32_t leaf = -1 - link[sd];
+                        float fl;
+                        memcpy(&fl, &leaf, 4);
+                        flat.push_back(make_float4(bmin[sd][0], bmin[sd][1], bmin[sd][2], bmax[sd][0]));
+                        flat.push_back(make_float4(bmax[sd][1], bmax[sd][2], fl, 0.f));
+                    }
+                }
+            };
+            if (ok) walk(d->top_root);
+            if (!ok || flat.size() > 64) flat.clear();
+            sc.n_flat = (int32_t)(flat.size() / 2);
+            if (flat.empty()) flat.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+            section(flat.data(), flat.size() * sizeof(float4), 7);
+            if (c->debug) fprintf(stderr, "[rtgpu] flat top-level pass: %d leaves\n", sc.n_flat);
         }
         blob.resize((blob.size() + 15) & ~(size_t)15);
         const uint8_t* db = nullptr;

@@ -233,6 +233,8 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
     for knob, value in (("RT_NO_LEAF_SPLIT", "1"), ("RT_FORCE_LEAF_SPLIT", "1"), ("RT_TOP_MIN", "1"), ("RT_TOP_MIN", "48"),
                         ("RT_TOP_GLOBAL", "1"), ("RT_FRONT", "1"), ("RT_FRONT", "0"),       # ... with and without the front pass
                         ("RT_NO_TOP_SPLIT", "1"),                                        # ... top-level leaves scanned object by object (no sub-trees over their objects)
+                        ("RT_NO_FLAT_TOP", "1"),                                         # ... the top-level tree walked node by node instead of the flat pass over its leaves' own boxes
+                        ("RT_SEPARATE_HASH", "1"),                                       # ... the shared rounds of the counter RNG in a pass of their own (k_hash_records) instead of inside k_closest
                         ("RT_SEPARATE_RAYGEN", "1"),                                     # ... primaries written out by k_raygen instead of made inside k_closest
                         ("RT_WIDE_CLOSEST", "0"), ("RT_WIDE_CLOSEST", "1"),                # ... closest hits over the reference's binary tree only / over the 4-wide quantised one in every launch (default: bounced batches)
                         ("RT_NO_CULL", "1")):                                            # ... every hit shaded and every path followed, however little it carries
