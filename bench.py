@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--cpu-crop", type=int, default=256, help="side of the centred crop the CPU baseline renders (SURVEY 8(d): 256)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the C3/C4 frames")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "samples"], help="how N ranks split the frame: tiles (default: disjoint 32x32 tiles, one all-gather of packed slabs) or samples (every rank renders its samples of every pixel, one all-reduce of the fixed-point accumulators: for frames in which a few pixels dominate, SURVEY 8(e))")
     ap.add_argument("--tree-mode", type=int, default=0, help="1: binned-SAH mesh tree, 2: linear BVH built on the GPU (free topology: NOT the reference's answers, SURVEY 8(f).2); never the default")
     args = ap.parse_args()
 
@@ -173,13 +174,21 @@ def main():
     ctx.set_camera(cam)
     params = rt.make_params(W, H, spp=args.spp, max_depth=args.depth, light_samples=35, shadow_mode=0, jitter=1, seed=0)
     dev = f"cuda:{local_rank}"
-    tiles = rtd.shard_tiles(W, H, rank, world, 32)
+    by_samples = args.shard == "samples" and world > 1
+    tiles = rtd.shard_tiles(W, H, 0, 1, 32) if by_samples else rtd.shard_tiles(W, H, rank, world, 32)
     gather = rtd.FrameGather(W, H, world, dev, 32)
+    reduce_samples = rtd.SampleReduce(W, H, world, dev) if by_samples else None
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
 
     tiles = np.asarray(tiles, np.int32).reshape(-1, 4)
 
     def step():
+        if by_samples:
+            ctx.begin_frame_samples(params, *rtd.sample_range(rank, world, args.spp))
+            ctx.render_tiles(tiles)                # every tile, this rank's samples
+            reduce_samples(ctx)                    # RCCL all-reduce(sum) of the int64 accumulators (+ flag words)
+            ctx.resolve_device(frame.data_ptr())   # every rank resolves the same sums: the whole frame
+            return ctx.stats()
         ctx.begin_frame(params)
         ctx.render_tiles(tiles)                    # this rank's tiles, queued with one call
         ctx.resolve_device(frame.data_ptr())       # runs the queued tiles, writes this rank's pixels
@@ -310,8 +319,9 @@ def main():
                 roof["reference_algorithm_equiv_GBps"] = round(bpr * rays_per_launch / avg_s / 1e9, 1)
         cfg = {"tree_mode": args.tree_mode, "workload": f"C5: synthetic {args.ntris}-triangle soup, {W}x{H}, {args.spp} spp, soft shadows "
                            f"(35 samples/light), depth {args.depth}, mesh BVH depth {args.mesh_depth}, counter RNG",
-               "tiles": "32x32, round-robin per tile row with a hashed row offset", "parallelism": f"tile-sharded x{world}",
-               "gather": f"all-gather of packed tile slabs, {gather.bytes_sent_per_rank()} B per rank" if world > 1 else "none (one rank)",
+               "tiles": "32x32, round-robin per tile row with a hashed row offset", "parallelism": f"{'sample' if by_samples else 'tile'}-sharded x{world}",
+               "gather": (f"all-reduce of the fixed-point accumulators, {reduce_samples.bytes_reduced_per_rank()} B per rank" if by_samples else
+                          f"all-gather of packed tile slabs, {gather.bytes_sent_per_rank()} B per rank") if world > 1 else "none (one rank)",
                "rays_per_frame": {"primary": prim // args.steps, "secondary": sec // args.steps, "shadow": shad // args.steps},
                "kernel_ms_per_step": {"k_shadow": round(ms_shadow / args.steps, 2), "k_closest": round(ms_closest / args.steps, 2)},
                "scene_build_s": round(t_build, 2), "upload_s": round(t_upload, 2), "frame_checksum": checksum,

@@ -187,6 +187,17 @@ int rt_begin_frame(rt_ctx*, const rt_render_params*);
  * far. Passes of 4 + 4 + 8 samples leave the bits of one 16-sample frame (same sample numbers, same counter-RNG streams,
  * order-independent sums). Image size, camera and the other parameters stay those of rt_begin_frame. */
 int rt_continue_frame(rt_ctx*, int32_t more_spp);
+/* Sample sharding across contexts (one per GPU / rank; SURVEY 8(e): the reduce(sum) route for frames in which a few pixels dominate, where a
+ * deal of tiles leaves the ranks unequal work). No counterpart in the reference, whose ThreadPool shares one image. rt_begin_frame_samples
+ * opens a frame of p->spp samples per pixel of which THIS context renders samples first_sample .. first_sample + n_samples - 1 (of every tile
+ * it is given: normally the whole image). Samples keep their numbers -- jitter and light-sampling streams are those of the undivided frame --
+ * and the accumulators are order-independent fixed point, so after the contexts' accumulators have been added (rt_export_accumulators into
+ * caller-owned DEVICE buffers: img_w*img_h*3 int64, img_w*img_h uint32 flag words; an all-reduce(sum) of the first and a bitwise OR of the
+ * second; rt_import_accumulators) every resolve returns the bits of the frame one context renders alone. ray-tracing_amd/dist.py
+ * (SampleReduce) does this over RCCL. Primary-hit ids are sample 0's: the context whose range starts at 0 has them. */
+int rt_begin_frame_samples(rt_ctx*, const rt_render_params*, int32_t first_sample, int32_t n_samples);
+int rt_export_accumulators(rt_ctx*, void* d_acc_i64, void* d_flags_u32);
+int rt_import_accumulators(rt_ctx*, const void* d_acc_i64, const void* d_flags_u32);
 /* Queues the pixels [x0,x0+w) x [y0,y0+h) (the per-pixel ThreadPool tasks of main.cpp:210-225).
  * Asynchronous: the work runs at the next rt_download_framebuffer / rt_resolve_device / rt_flush. */
 int rt_render_tile(rt_ctx*, int x0, int y0, int w, int h);

@@ -115,7 +115,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
                       ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", "<f4"), ("v", "<f4")])
 
 # every symbol include/rtgpu.h and include/rthost.h declare
-EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame", "rt_continue_frame",
+EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame", "rt_begin_frame_samples", "rt_export_accumulators", "rt_import_accumulators", "rt_continue_frame",
            "rt_render_tile", "rt_render_tiles", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_resolve_rgba8_device", "rt_get_stats",
            "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion", "rt_filter_passes",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
@@ -149,6 +149,9 @@ def lib():
     L.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.rt_begin_frame.argtypes = [vp, C.POINTER(RenderParams)]
     L.rt_continue_frame.argtypes = [vp, i32]
+    L.rt_begin_frame_samples.argtypes = [vp, C.POINTER(RenderParams), i32, i32]
+    L.rt_export_accumulators.argtypes = [vp, vp, vp]
+    L.rt_import_accumulators.argtypes = [vp, vp, vp]
     L.rt_render_tile.argtypes = [vp, i32, i32, i32, i32]
     L.rt_render_tiles.argtypes = [vp, vp, i64]
     L.rt_flush.argtypes = [vp]
@@ -397,6 +400,18 @@ class Context:
     def begin_frame(self, params):
         self.params = params
         self._check(self.L.rt_begin_frame(self.h, C.byref(params)), "rt_begin_frame")
+
+    def begin_frame_samples(self, params, first_sample, n_samples):
+        """Sample sharding: this context renders samples first_sample .. first_sample + n_samples - 1 of a frame of params.spp."""
+        self.params = params
+        self._check(self.L.rt_begin_frame_samples(self.h, C.byref(params), int(first_sample), int(n_samples)), "rt_begin_frame_samples")
+
+    def export_accumulators(self, acc_ptr, flags_ptr):
+        """The frame's fixed-point sums (int64, 3 per pixel) and flag words (uint32 per pixel) into device buffers of the caller."""
+        self._check(self.L.rt_export_accumulators(self.h, C.c_void_p(acc_ptr), C.c_void_p(flags_ptr)), "rt_export_accumulators")
+
+    def import_accumulators(self, acc_ptr, flags_ptr):
+        self._check(self.L.rt_import_accumulators(self.h, C.c_void_p(acc_ptr), C.c_void_p(flags_ptr)), "rt_import_accumulators")
 
     def continue_frame(self, more_spp):
         """Progressive accumulation: the tiles queued from here on add more_spp samples per pixel to the open frame."""

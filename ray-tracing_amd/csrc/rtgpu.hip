@@ -70,6 +70,7 @@ struct rt_ctx {
     FrameD fr{};
     std::vector<TileD> tiles;
     unsigned long long queued_samples = 0;
+    int32_t resolve_spp = 0;        /* sample-sharded frames (rt_begin_frame_samples): the frame's samples per pixel over ALL contexts, what a resolve divides by; 0 = this context's own count */
 
     DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays, dtex, ovf;
     uint32_t batch = 32u << 20;   /* path states per wavefront iteration at most (RT_BATCH). One batch of diffuse hits is one launch of the persistent shadow kernel, and
@@ -2063,8 +2064,54 @@ int rt_begin_frame(rt_ctx* c, const rt_render_params* p) {
     HIP_TRY(c, hipMemsetAsync(c->nf.p, 0, npix * sizeof(uint32_t), c->stream));
     c->tiles.clear();
     c->queued_samples = 0;
+    c->resolve_spp = 0;
     memset(&c->stats, 0, sizeof(c->stats));
     c->has_frame = true;
+    return RT_OK;
+}
+
+/* Sample sharding ("when a few pixels dominate"): this context renders samples first .. first + count - 1 of every pixel
+ * it is given, of a frame of p->spp samples per pixel that several contexts (ranks) share. The samples keep their numbers, hence their
+ * jitter and their counter-RNG streams, and the sums are order-independent fixed point: once the accumulators of the contexts have been
+ * added (rt_export_accumulators, all-reduce, rt_import_accumulators) a resolve gives the bits of the frame one context would have
+ * rendered alone. Primary-hit ids belong to sample 0, i.e. to the context whose range starts at 0. */
+int rt_begin_frame_samples(rt_ctx* c, const rt_render_params* p, int32_t first_sample, int32_t n_samples) {
+    if (!c || !p) return RT_ERR_ARG;
+    if (!c->subs.empty()) return fail(c, RT_ERR_ARG, "rt_begin_frame_samples: one device per context (the ranks of ray-tracing_amd/dist.py)");
+    if (first_sample < 0 || n_samples < 1 || (long long)first_sample + n_samples > (long long)p->spp) return fail(c, RT_ERR_ARG, "rt_begin_frame_samples: sample range outside the frame's %d samples", p->spp);
+    int rc = rt_begin_frame(c, p);
+    if (rc) return rc;
+    c->fr.sample_base = first_sample;
+    c->fr.spp = n_samples;
+    c->resolve_spp = p->spp;
+    return RT_OK;
+}
+
+/* the frame's accumulators, out of the context and back in: 3 x int64 per pixel (2^-36 units) and one flag word per pixel (three bits per
+ * channel: NaN, +inf, -inf seen), both in DEVICE memory of the caller. Export runs what is queued first. */
+int rt_export_accumulators(rt_ctx* c, void* d_acc, void* d_flags) {
+    if (!c || !d_acc || !d_flags) return RT_ERR_ARG;
+    if (!c->subs.empty()) return fail(c, RT_ERR_ARG, "rt_export_accumulators: one device per context");
+    if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_export_accumulators before rt_begin_frame");
+    int rc = rt_flush(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)c->fr.img_w * c->fr.img_h;
+    HIP_TRY(c, hipMemcpyAsync(d_acc, c->acc.p, npix * 3 * sizeof(long long), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_flags, c->nf.p, npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+int rt_import_accumulators(rt_ctx* c, const void* d_acc, const void* d_flags) {
+    if (!c || !d_acc || !d_flags) return RT_ERR_ARG;
+    if (!c->subs.empty()) return fail(c, RT_ERR_ARG, "rt_import_accumulators: one device per context");
+    if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_import_accumulators before rt_begin_frame");
+    if (!c->tiles.empty()) return fail(c, RT_ERR_STATE, "rt_import_accumulators with tiles queued (they would add to the imported sums)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)c->fr.img_w * c->fr.img_h;
+    HIP_TRY(c, hipMemcpyAsync(c->acc.p, d_acc, npix * 3 * sizeof(long long), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->nf.p, d_flags, npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -2073,6 +2120,7 @@ int rt_continue_frame(rt_ctx* c, int32_t more_spp) {
     if (!c) return RT_ERR_ARG;
     if (!c->has_frame) return fail(c, RT_ERR_STATE, "rt_continue_frame before rt_begin_frame");
     if (more_spp < 1 || (long long)c->fr.sample_base + c->fr.spp + more_spp > 0x00FFFFFFll) return fail(c, RT_ERR_ARG, "rt_continue_frame: samples per pixel out of range");
+    if (c->resolve_spp > 0) return fail(c, RT_ERR_STATE, "rt_continue_frame on a sample-sharded frame (rt_begin_frame_samples)");
     int rc = rt_flush(c);                                   /* what is queued belongs to the pass that ends here */
     if (rc) return rc;
     if (!c->subs.empty()) {
@@ -2238,7 +2286,7 @@ int rt_resolve_device(rt_ctx* c, void* d_rgb) {
     HIP_TRY(c, hipSetDevice(c->device));        /* (rt_flush returns before its own hipSetDevice when nothing is queued, and this may run on a worker thread of on_all) */
     uint32_t npix = (uint32_t)((size_t)c->fr.img_w * c->fr.img_h);
     hipLaunchKernelGGL(k_resolve, dim3((npix * 3 + 255) / 256), dim3(256), 0, c->stream, static_cast<const long long*>(c->acc.p),
-                       static_cast<const uint32_t*>(c->nf.p), npix, c->fr.sample_base + c->fr.spp, static_cast<float*>(d_rgb));
+                       static_cast<const uint32_t*>(c->nf.p), npix, c->resolve_spp > 0 ? c->resolve_spp : c->fr.sample_base + c->fr.spp, static_cast<float*>(d_rgb));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     return RT_OK;

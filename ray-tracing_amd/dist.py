@@ -103,6 +103,68 @@ class FrameGather:
         return frame
 
 
+def sample_range(rank, world, spp):
+    """Sample sharding: the samples (first, count) of every pixel that `rank` renders; the ranges of all ranks tile 0 .. spp - 1."""
+    first = rank * spp // world
+    return first, (rank + 1) * spp // world - first
+
+
+class SampleReduce:
+    """Sample sharding: every rank renders a sample subset of EVERY pixel (rt_begin_frame_samples), the ranks'
+    fixed-point accumulators are added with one all-reduce(sum) and their non-finite flag words OR-ed, and every rank resolves
+    the same frame -- the bits of a single-GPU render, because the sums are integers. For frames in which a few pixels own most
+    of the rays (the default scene: depth-50 recursion in the glass gorilla), where dealing tiles leaves ranks unequal work.
+
+    RCCL has no bitwise OR: the nine flag bits of a pixel (NaN / +inf / -inf seen, per channel) travel as nine 7-bit counters in
+    one int64 (world <= 64) and are turned back into bits after the sum."""
+
+    def __init__(self, width, height, world, device):
+        import torch
+        assert world <= 64
+        self.world = world
+        self.acc = torch.zeros((height, width, 3), dtype=torch.int64, device=device)
+        self.flags = torch.zeros((height, width), dtype=torch.int32, device=device)
+
+    def bytes_reduced_per_rank(self):
+        return self.acc.numel() * 8 + self.flags.numel() * 8
+
+    @staticmethod
+    def spread_flags(flags):
+        """uint32 flag words (as int32) -> int64 with bit b of the word at bit 7 b."""
+        import torch
+        f = flags.to(torch.int64) & 0x1FF
+        out = torch.zeros_like(f)
+        for b in range(9):
+            out |= ((f >> b) & 1) << (7 * b)
+        return out
+
+    @staticmethod
+    def gather_flags(counts):
+        """the inverse after a sum: bit b set iff counter b is not zero."""
+        import torch
+        out = torch.zeros_like(counts)
+        for b in range(9):
+            out |= (((counts >> (7 * b)) & 0x7F) != 0).to(torch.int64) << b
+        return out.to(torch.int32)
+
+    def reduce_tensors(self, acc, flags):
+        """In place: acc (int64) summed over the ranks, flags (int32 flag words) OR-ed over the ranks."""
+        import torch.distributed as dist
+        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return acc, flags
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        counts = self.spread_flags(flags)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        flags.copy_(self.gather_flags(counts))
+        return acc, flags
+
+    def __call__(self, ctx):
+        """ctx: this rank's Context with its share of the samples queued or rendered. Afterwards ctx holds the whole frame's sums."""
+        ctx.export_accumulators(self.acc.data_ptr(), self.flags.data_ptr())
+        self.reduce_tensors(self.acc, self.flags)
+        ctx.import_accumulators(self.acc.data_ptr(), self.flags.data_ptr())
+
+
 def sum_counters(values, device=None):
     """All-reduce a small list of integer counters (ray counts)."""
     import torch

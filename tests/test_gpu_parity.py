@@ -631,3 +631,80 @@ def test_contribution_culling_does_not_change_a_bit(rt, ctx, monkeypatch):
     assert cst.rays_secondary < fst.rays_secondary and cst.rays_primary == fst.rays_primary
     assert cst.shadow_queries <= fst.rays_shadow          # (hits below culled path states are not even counted)
     print(f"rays traced with / without culling: {cst.rays} / {fst.rays}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,depth,zoom", [("final", 50, 25.0), ("cornell_box", 50, 3.0), ("mesh_gorilla", 50, 3.0), ("no light", 50, 3.0)])
+def test_sample_sharded_contexts_add_up_to_the_one_context_frame(rt, ctx, name, depth, zoom):
+    """Sample sharding (rt_begin_frame_samples): three contexts -- three ranks -- render disjoint sample ranges of every
+    pixel; their accumulators, added (integers) and their flag words OR-ed, resolve to the BITS of the frame one context renders alone,
+    non-finite pixels (cornell box: normal maps) included. The addition is done on the host here; dist.SampleReduce does it with an
+    all-reduce (tests/test_multigpu_gloo.py)."""
+    import ctypes
+    import importlib
+    rtd = importlib.import_module("ray-tracing_amd.dist")
+    # caller-owned device memory from the HIP runtime the library itself uses (by soname, as tests/test_progressive.py does; torch's
+    # bundled runtime must not be initialised beside it in this process)
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    if name == "no light":
+        # a scene without lights: the reference's shadow factor is 1 - 0/0 (Scene.h:211-222), every diffuse hit a NaN -> the flag words matter
+        hs = rt.HostScene()
+        hs.add_sphere([0.0, 0.0, 0.0], 1.0, rt.make_material(kd=(0.8, 0.2, 0.2), shininess=8.0))
+        hs.add_sphere([1.5, 0.5, -1.0], 0.7, rt.make_material(kd=(1, 1, 1), type=2, reflectivity=0.8))
+        hs.build(3, 12)
+        ctx.upload_scene(hs)
+    else:
+        hs, _ = scene_pair(rt, ctx, name)
+    W, H, SPP = 96, 64, 7
+    cam = rt.default_camera(W / H, zoom=zoom)
+    p = rt.make_params(W, H, spp=SPP, max_depth=depth, light_samples=35, shadow_mode=0, jitter=1, seed=6)
+    want, wprim, wst = ctx.render(cam, p)
+    world = 3
+    d_acc, d_flags = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_acc), W * H * 3 * 8) == 0 and hip.hipMalloc(ctypes.byref(d_flags), W * H * 4) == 0
+    acc, flags = np.zeros((H, W, 3), np.int64), np.zeros((H, W), np.uint32)
+    tot_acc, tot_flags = np.zeros_like(acc), np.zeros_like(flags)
+    rays = [0, 0, 0]
+    ranks = []
+    try:
+        for r in range(world):
+            c = rt.Context(0)
+            ranks.append(c)
+            c.upload_scene(hs)
+            c.set_camera(cam)
+            first, count = rtd.sample_range(r, world, SPP)
+            c.begin_frame_samples(p, first, count)
+            c.render_tiles(rt.interleaved_tiles(W, H))
+            c.export_accumulators(d_acc.value, d_flags.value)
+            assert hip.hipMemcpy(acc.ctypes.data, d_acc, acc.nbytes, 2) == 0 and hip.hipMemcpy(flags.ctypes.data, d_flags, flags.nbytes, 2) == 0
+            tot_acc += acc
+            tot_flags |= flags
+            st = c.stats()
+            rays = [rays[0] + st.rays_primary, rays[1] + st.rays_secondary, rays[2] + st.shadow_queries]
+        assert rays[0] == wst.rays_primary == W * H * SPP
+        assert hip.hipMemcpy(d_acc, tot_acc.ctypes.data, tot_acc.nbytes, 1) == 0 and hip.hipMemcpy(d_flags, tot_flags.ctypes.data, tot_flags.nbytes, 1) == 0
+        got = []
+        for c in ranks:                       # every rank resolves the same frame
+            c.import_accumulators(d_acc.value, d_flags.value)
+            rgb, prim, _ = c.download()
+            got.append((rgb, prim))
+    finally:
+        for c in ranks:
+            c.close()
+        hip.hipFree(d_acc)
+        hip.hipFree(d_flags)
+    for rgb, _ in got:
+        assert np.array_equal(rgb.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got[0][1], wprim)                       # sample 0 is rank 0's: it has the primary-hit ids
+    assert (got[1][1] == 0xFFFFFFFF).all()
+    if name == "no light":
+        assert np.isnan(want).any() and np.isfinite(want).any()
+    # misuse is refused
+    with pytest.raises(rt.RtError):
+        ctx.begin_frame_samples(p, 5, 3)                          # 5 + 3 > 7
+    ctx.begin_frame_samples(p, 0, 3)
+    with pytest.raises(rt.RtError):
+        ctx.continue_frame(1)

@@ -96,3 +96,49 @@ def test_tile_deal_is_a_balanced_partition_and_not_column_stripes(world):
     for ty in range(nty):
         row = np.bincount(owner[ty], minlength=world)
         assert row.max() - row.min() <= 1
+
+
+def _sample_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    rtd = importlib.import_module("ray-tracing_amd.dist")
+    rtd.init("gloo")
+    W, H = 40, 24
+    g = torch.Generator().manual_seed(100 + rank)
+    acc = torch.randint(-2**40, 2**40, (H, W, 3), generator=g, dtype=torch.int64)
+    flags = torch.zeros((H, W), dtype=torch.int32)
+    pick = torch.rand((H, W), generator=g) < 0.05
+    flags[pick] = torch.randint(0, 512, (int(pick.sum()),), generator=g, dtype=torch.int32)
+    np.save(os.path.join(out_dir, f"acc_in_{rank}.npy"), acc.numpy())
+    np.save(os.path.join(out_dir, f"flags_in_{rank}.npy"), flags.numpy())
+    red = rtd.SampleReduce(W, H, world, "cpu")
+    red.reduce_tensors(acc, flags)
+    np.save(os.path.join(out_dir, f"acc_out_{rank}.npy"), acc.numpy())
+    np.save(os.path.join(out_dir, f"flags_out_{rank}.npy"), flags.numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sample_sharded_accumulators_reduce_to_sum_and_or(world, tmp_path):
+    """The collective of the sample-sharded route (dist.SampleReduce): int64 sums added, flag words OR-ed (as 7-bit counters
+    through a sum: RCCL has no bitwise OR). The render side of it -- two sample ranges add up to the bits of one frame -- needs
+    the device and is tests/test_gpu_parity.py::test_sample_sharded_contexts_add_up_to_the_one_context_frame."""
+    rtd = importlib.import_module("ray-tracing_amd.dist")
+    assert [rtd.sample_range(r, 8, 30) for r in range(8)] == [(0, 3), (3, 4), (7, 4), (11, 4), (15, 3), (18, 4), (22, 4), (26, 4)]
+    for spp in (1, 5, 16, 30):
+        for w in (1, 2, 3, 8):
+            rs = [rtd.sample_range(r, w, spp) for r in range(w)]
+            assert rs[0][0] == 0 and sum(c for _, c in rs) == spp and all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+    f = torch.arange(512, dtype=torch.int32)
+    assert torch.equal(rtd.SampleReduce.gather_flags(rtd.SampleReduce.spread_flags(f) * 64), f)       # 64 ranks with the same bit: no carry
+    mp.spawn(_sample_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want_acc = sum(np.load(tmp_path / f"acc_in_{r}.npy") for r in range(world))
+    want_flags = np.zeros_like(np.load(tmp_path / "flags_in_0.npy"))
+    for r in range(world):
+        want_flags |= np.load(tmp_path / f"flags_in_{r}.npy")
+    assert want_flags.any()
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"acc_out_{r}.npy"), want_acc)
+        assert np.array_equal(np.load(tmp_path / f"flags_out_{r}.npy"), want_flags)
