@@ -127,6 +127,9 @@ struct DScene {
      * rays share (rt_rng_prefix) instead of the path code, so that no pass over the records (k_hash_records) is needed for it */
     int32_t rng_hash;
     uint32_t rng_seed;
+    /* per launch: k_closest takes one state per 2^spread_shift lanes (the others stay idle). A small batch of bounced rays is
+     * latency-bound, and the lanes of a wave serialise their divergent walks: spread over more waves the batch ends sooner */
+    int32_t spread_shift;
 };
 /* head of section 6 of top_blob, in front of tsub */
 struct TopFrame {

@@ -803,6 +803,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
     extern __shared__ __align__(16) int s_stack[];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n;
+    if (!FRESH && sc.spread_shift > 0) {         /* (a small batch: one state per 2^shift lanes, see DScene::spread_shift) */
+        active = (i & ((1u << sc.spread_shift) - 1u)) == 0u && (i >> sc.spread_shift) < n;
+        i >>= sc.spread_shift;
+    }
     int* stk = s_stack + threadIdx.x;
     const int stride = blockDim.x;
 
@@ -1046,6 +1050,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
 #endif
 #ifndef RT_TRI_STEPS
 #define RT_TRI_STEPS 4        /* triangle-phase steps per round */
+#endif
+/* the same knobs for the variant with the flat top-level pass (k_shadow<5>: many objects, short walks) */
+#ifndef RT_REFILL_MIN_FLAT
+#define RT_REFILL_MIN_FLAT 16
+#endif
+#ifndef RT_TRI_MIN_FLAT
+#define RT_TRI_MIN_FLAT 24
+#endif
+#ifndef RT_NODE_STEPS_FLAT
+#define RT_NODE_STEPS_FLAT 12
+#endif
+#ifndef RT_EXACT_MIN_FLAT
+#define RT_EXACT_MIN_FLAT 8
 #endif
 
 #define TS_MODE 1u
@@ -1697,6 +1714,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         tt.flat = reinterpret_cast<const float4*>(base + sc.top_off[7]);
         wst.tf = tt.tf;
     }
+    /* (a launch with fewer rays than the grid could take RT_GRAB at a time would leave most waves without any) */
+    const unsigned long long grab = total >= (unsigned long long)gridDim.x * RT_GRAB ? (unsigned long long)RT_GRAB
+                                    : (total / gridDim.x < 64ull ? 64ull : (total / gridDim.x) & ~63ull);
     ShadowLane s;
     s.st = ST_IDLE;
     s.tri_pos = TRI_NONE;
@@ -1707,7 +1727,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     for (;;) {
         if (count_steps) k_t0 = __builtin_readcyclecounter();
         unsigned long long idle = __builtin_amdgcn_ballot_w64(s.st == ST_IDLE);
-        if ((!exhausted || wpos < wend) && (__popcll(idle) >= (MODE == 2 ? RT_REFILL_MIN_SUB : RT_REFILL_MIN))) {
+        if ((!exhausted || wpos < wend) && (__popcll(idle) >= (MODE == 2 ? RT_REFILL_MIN_SUB : FLAT ? RT_REFILL_MIN_FLAT : RT_REFILL_MIN))) {
             /* ray indices come from a wave-local range [wpos, wend) that is topped up RT_GRAB rays at a time: one
              * atomic on the single global counter per RT_GRAB rays instead of one per refill (same-address
              * device-scope atomics serialise) */
@@ -1719,11 +1739,11 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             else if (exhausted) { if (rank >= avail) idx = total; wpos = wend; }
             else {
                 unsigned long long nb = 0;
-                if (lane == 0) nb = atomicAdd(next, (unsigned long long)RT_GRAB);
+                if (lane == 0) nb = atomicAdd(next, grab);
                 nb = __shfl(nb, 0);
                 if (rank >= avail) idx = nb + (rank - avail);
                 wpos = nb + (n - avail);
-                wend = nb + RT_GRAB;
+                wend = nb + grab;
                 if (wend >= total) {
                     exhausted = true;
                     wend = nb < total ? total : nb;
@@ -1761,7 +1781,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         if (count_steps) { k_t1 = __builtin_readcyclecounter(); k_top += k_t1 - k_t0; k_t0 = k_t1; }
         /* node phase */
 #pragma unroll 1
-        for (int k = 0; k < RT_NODE_STEPS; k++) {
+        for (int k = 0; k < (FLAT ? RT_NODE_STEPS_FLAT : RT_NODE_STEPS); k++) {
             /* a lane walks while it has a node to visit or something to pop, also with one leaf pending; it is
              * blocked only by a second leaf or when nothing is left but the pending leaf */
             const bool walking = s.st == ST_MESH, waiting = s.st == ST_BLOCKED;
@@ -1779,7 +1799,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const bool pend = s.st >= ST_MESH && s.tri_pos != TRI_NONE;
             const int np = __popcll(__builtin_amdgcn_ballot_w64(pend)), nw = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_MESH));
             const int nb = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_BLOCKED));
-            if (np < RT_TRI_MIN && nw > nb && nw > 0) continue;
+            if (np < (FLAT ? RT_TRI_MIN_FLAT : RT_TRI_MIN) && nw > nb && nw > 0) continue;
         }
 #pragma unroll 1
         for (int k = 0; k < RT_TRI_STEPS; k++) {
@@ -1794,7 +1814,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const bool cand = s.st >= ST_MESH && s.tri_pos != TRI_NONE && (s.tri_pos & TRI_EXACT);
             const int nc = __popcll(__builtin_amdgcn_ballot_w64(cand));
             const int nw = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_MESH)), nb = __popcll(__builtin_amdgcn_ballot_w64(s.st == ST_BLOCKED));
-            if (nc > 0 && (nc >= RT_EXACT_MIN || nw <= nb)) {
+            if (nc > 0 && (nc >= (FLAT ? RT_EXACT_MIN_FLAT : RT_EXACT_MIN) || nw <= nb)) {
                 if (count_steps) { c_iter++; if (threadIdx.x == 0) c_wtop++; if (cand) c_other++; }
                 if (cand) shadow_quant_exact_step(sc, s, cnt);
             }

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <functional>
 #include <new>
+#include <chrono>
 #include <set>
 #include <tuple>
 #include <string>
@@ -80,6 +81,7 @@ struct rt_ctx {
     unsigned long long mem_budget = 96ull << 30;    /* bytes the buffers of the wavefront loop may take together (RT_MEM_BUDGET_GB; HBM is 288 GB) */
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
+    unsigned long long spread_lanes = 131072;      /* run_wavefront: lanes a small batch of bounced rays is spread over (RT_SPREAD_LANES, 0 = one state per lane always) */
     int wide_mode = 2;              /* closest hits over the 4-wide quantised tree: 0 never, 1 always, 2 for batches of bounced rays and rt_intersect (RT_WIDE_CLOSEST=0|1 overrides; see run_wavefront) */
     int cstack_wide = 0;            /* per-lane stack entries of that walk (three pending links per level); DScene::cstack_cap is what the binary walk needs */
     bool separate_raygen = false;   /* test knob RT_SEPARATE_RAYGEN=1: k_raygen writes the primaries out and k_closest loads them (the two ways must agree bit for bit) */
@@ -320,6 +322,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
     uint32_t cblock = cblock_light;
     if (const char* e = getenv("RT_CBLOCK")) { int v = atoi(e); if ((v == 64 || v == 128 || v == 256) && lds_bytes_closest(c, v) + 64 <= c->lds_max) cblock = (uint32_t)v; }
 
+    const auto t_loop0 = std::chrono::steady_clock::now();     /* (RT_DEBUG prints each iteration's time since here) */
     while (done < src.total || top > 0) {
         /* 1. top up with fresh primaries */
         uint32_t room = top < B ? (uint32_t)(B - top) : 0u;
@@ -362,9 +365,15 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         scl.rng_hash = fuse_hash ? 1 : 0; scl.rng_seed = c->fr.seed;
         scl.wide_closest = (c->sc.wide_closest && (c->wide_mode == 1 || (c->wide_mode == 2 && 2ull * n_new < nb))) ? 1 : 0;
         const bool wide = scl.wide_closest != 0;
+        /* a small batch of bounced rays (the depth-50 tail of a glass mesh: a few hundred states per iteration, fifty iterations)
+         * is spread one state per 2^shift lanes over up to spread_lanes lanes */
+        uint32_t spread = 0;
+        if (n_new == 0 && cblock == 64u) while (spread < 6 && ((unsigned long long)nb << (spread + 1)) <= c->spread_lanes) spread++;
+        scl.spread_shift = (int32_t)spread;
+
         if (wide && cblock > 64u && lds_bytes_closest(c, cblock, true) + 64 > c->lds_max) cblock = 64u;
         auto launch_closest = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((nb + cblock - 1) / cblock), dim3(cblock), lds_bytes_closest(c, cblock, wide) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, scl, stack + base, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
+            hipLaunchKernelGGL(kern, dim3((uint32_t)((((unsigned long long)nb << spread) + cblock - 1) / cblock)), dim3(cblock), lds_bytes_closest(c, cblock, wide) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, scl, stack + base, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
                                w.child, 2 * B, w.drec, w.dcode, w.dtex, B, d_ctr, acc, nonfinite, prim, fresh);
         };
         fresh.n_old = nb - n_new;
@@ -395,8 +404,9 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         uint32_t n_child = c->h_ctr->n_child, n_diff = c->h_ctr->n_diffuse;
         c->stats.rays_primary += n_new;                 /* the fresh primaries sit on top of the stack: all of them are in this batch */
         c->stats.rays_secondary += nb - n_new;
-        if (c->debug) fprintf(stderr, "[rtgpu] iter %llu: new %u batch %u -> children %u diffuse %u (stack %zu)\n",
-                              (unsigned long long)c->stats.iterations, n_new, nb, n_child, n_diff, top);
+        if (c->debug) fprintf(stderr, "[rtgpu] iter %llu: new %u batch %u -> children %u diffuse %u (stack %zu) at %.1f us\n",
+                              (unsigned long long)c->stats.iterations, n_new, nb, n_child, n_diff, top,
+                              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count());
         if (n_child > 2 * B || n_diff > B) return fail(c, RT_ERR_LIMIT, "queue overflow (%u children, %u diffuse)", n_child, n_diff);
         /* 3. shadow + Phong for the diffuse records of this batch */
         if (n_diff && L > 0) {
@@ -1192,6 +1202,7 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
         c->separate_raygen = getenv("RT_SEPARATE_RAYGEN") != nullptr;
         const char* pb = getenv("RT_PERSISTENT_BLOCKS");
         if (pb && atoi(pb) > 0) c->persistent_blocks = atoi(pb);
+        if (const char* e = getenv("RT_SPREAD_LANES")) c->spread_lanes = strtoull(e, nullptr, 10);
     }
     *out = c;
     return RT_OK;
