@@ -790,6 +790,18 @@ __global__ void __launch_bounds__(256) k_seed(const float* org, const float* dir
                 pixel[g], sample[g], 1ull, max_depth, 0u);
 }
 
+/* After k_closest, one thread: the two queue lengths (and, while the front pass is on trial, the deferred rays so far) go to the
+ * host's pinned counters and are zeroed for the next iteration -- one small launch instead of a fill and one or two copies
+ * per iteration of the wavefront loop (what a short iteration costs is its stream operations, not its rays). */
+__global__ void k_publish(Counters* ctr, Counters* host, int with_deferred) {
+    host->n_child = ctr->n_child;
+    host->n_diffuse = ctr->n_diffuse;
+    if (with_deferred) host->deferred_sum = ctr->deferred_sum;
+    ctr->n_child = 0u;
+    ctr->n_diffuse = 0u;
+    __threadfence_system();
+}
+
 /* Scene::rayTraceRecursive (Scene.h:174-280) for one path state: the recursion is unrolled into
  * child states carrying a throughput (radiance is linear in the child radiance, Scene.h:229,263-271). */
 /* FRESH: the states from number fresh.n_old on are primaries of the queued tiles that no kernel has written out: the lane

@@ -81,12 +81,14 @@ struct rt_ctx {
     unsigned long long mem_budget = 96ull << 30;    /* bytes the buffers of the wavefront loop may take together (RT_MEM_BUDGET_GB; HBM is 288 GB) */
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
+    bool no_tail_swap = false;                     /* RT_NO_TAIL_SWAP (test knob): the children of every iteration are copied onto the stack */
     unsigned long long spread_lanes = 131072;      /* run_wavefront: lanes a small batch of bounced rays is spread over (RT_SPREAD_LANES, 0 = one state per lane always) */
     int wide_mode = 2;              /* closest hits over the 4-wide quantised tree: 0 never, 1 always, 2 for batches of bounced rays and rt_intersect (RT_WIDE_CLOSEST=0|1 overrides; see run_wavefront) */
     int cstack_wide = 0;            /* per-lane stack entries of that walk (three pending links per level); DScene::cstack_cap is what the binary walk needs */
     bool separate_raygen = false;   /* test knob RT_SEPARATE_RAYGEN=1: k_raygen writes the primaries out and k_closest loads them (the two ways must agree bit for bit) */
     int front_state = -1;       /* the front pass of the shadow rays (k_shadow_front): -1 = to be probed on this scene, 0 = off, 1 = on */
     Counters* h_ctr = nullptr;  /* pinned */
+    Counters* d_hctr = nullptr; /* ... as the device sees it (k_publish writes the queue lengths of an iteration there) */
     rt_stats stats{};
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
@@ -323,7 +325,13 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
     if (const char* e = getenv("RT_CBLOCK")) { int v = atoi(e); if ((v == 64 || v == 128 || v == 256) && lds_bytes_closest(c, v) + 64 <= c->lds_max) cblock = (uint32_t)v; }
 
     const auto t_loop0 = std::chrono::steady_clock::now();     /* (RT_DEBUG prints each iteration's time since here) */
-    while (done < src.total || top > 0) {
+    /* The tail of a frame -- no primaries left, the stack empty, the children of one batch fit the next -- does not go through
+     * the stack: the children of one iteration are the batch of the next where they lie, k_closest writing to the child
+     * buffer and to the (empty) stack buffer in turns. No copy per iteration then: a depth-50 path inside a glass mesh is fifty
+     * iterations of a few hundred states, and their stream operations are what they cost. */
+    PathState* alt_in = nullptr;
+    uint32_t alt_n = 0;
+    while (done < src.total || top > 0 || alt_n > 0) {
         /* 1. top up with fresh primaries */
         uint32_t room = top < B ? (uint32_t)(B - top) : 0u;
         uint32_t n_new = (uint32_t)std::min<unsigned long long>(src.total - done, room);
@@ -347,7 +355,15 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         uint32_t nb = (uint32_t)std::min<size_t>(top, B);
         size_t base = top - nb;
         top = base;
-        HIP_TRY(c, hipMemsetAsync(w.ctr, 0, 16, c->stream));    /* n_child, n_diffuse */
+        const PathState* in_ptr = stack + base;
+        PathState* out_ptr = w.child;
+        if (alt_n) {                       /* (top == 0 and n_new == 0 here) */
+            nb = alt_n; base = 0;
+            in_ptr = alt_in;
+            out_ptr = alt_in == w.child ? stack : w.child;
+            alt_in = nullptr; alt_n = 0;
+        }
+        /* (n_child and n_diffuse are zero here: the frame's fill above, then k_publish after every k_closest) */
         EventPair* e1 = nullptr;
         if (w.timing) {
             if (!(e1 = next_event(c, 0))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
@@ -373,8 +389,8 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
 
         if (wide && cblock > 64u && lds_bytes_closest(c, cblock, true) + 64 > c->lds_max) cblock = 64u;
         auto launch_closest = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((uint32_t)((((unsigned long long)nb << spread) + cblock - 1) / cblock)), dim3(cblock), lds_bytes_closest(c, cblock, wide) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, scl, stack + base, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
-                               w.child, 2 * B, w.drec, w.dcode, w.dtex, B, d_ctr, acc, nonfinite, prim, fresh);
+            hipLaunchKernelGGL(kern, dim3((uint32_t)((((unsigned long long)nb << spread) + cblock - 1) / cblock)), dim3(cblock), lds_bytes_closest(c, cblock, wide) + (cblock > 64u ? (2 * (cblock / 64) + 2) * sizeof(uint32_t) : 0), c->stream, scl, in_ptr, nb,   /* (no word more than needed: LDS comes in large granules, and a few bytes can cost two blocks per CU) */
+                               out_ptr, 2 * B, w.drec, w.dcode, w.dtex, B, d_ctr, acc, nonfinite, prim, fresh);
         };
         fresh.n_old = nb - n_new;
         const bool sub = c->sc.has_sub && c->sc.quant_ok;
@@ -386,8 +402,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         if (fuse_raygen && n_new) { if (wide) pick_closest(std::true_type{}, std::true_type{}); else pick_closest(std::true_type{}, std::false_type{}); }
         else { if (wide) pick_closest(std::false_type{}, std::true_type{}); else pick_closest(std::false_type{}, std::false_type{}); }
         if (e1) HIP_TRY(c, hipEventRecord(e1->b, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_ctr, w.ctr, 16, hipMemcpyDeviceToHost, c->stream));
-        if (c->front_state < 0 && front_rays) HIP_TRY(c, hipMemcpyAsync(&c->h_ctr->deferred_sum, &d_ctr->deferred_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, d_ctr, c->d_hctr, (c->front_state < 0 && front_rays) ? 1 : 0);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
         if (c->front_state < 0 && front_rays >= (16ull << 20)) {
@@ -508,12 +523,16 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         }
         /* 4. push the children */
         if (n_child) {
-            if (top + n_child > w.stack_cap) return fail(c, RT_ERR_LIMIT, "path-state stack overflow");
-            HIP_TRY(c, hipMemcpyAsync(stack + top, w.child, (size_t)n_child * sizeof(PathState), hipMemcpyDeviceToDevice, c->stream));
-            top += n_child;
+            if (top == 0 && done >= src.total && n_child <= B && !c->no_tail_swap) { alt_in = out_ptr; alt_n = n_child; }    /* the next batch, where it lies */
+            else if (out_ptr == stack) top = n_child;                   /* (written to the empty stack buffer: in place already) */
+            else {
+                if (top + n_child > w.stack_cap) return fail(c, RT_ERR_LIMIT, "path-state stack overflow");
+                HIP_TRY(c, hipMemcpyAsync(stack + top, w.child, (size_t)n_child * sizeof(PathState), hipMemcpyDeviceToDevice, c->stream));
+                top += n_child;
+            }
         }
         c->stats.iterations++;
-        c->stats.peak_states = std::max<uint64_t>(c->stats.peak_states, top);
+        c->stats.peak_states = std::max<uint64_t>(c->stats.peak_states, top + alt_n);
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, w.ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1184,6 +1203,7 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
     {   /* set-up that must not happen later: the pinned read-back block and this device's address of the static scratch */
         void* sp = nullptr;
         if (hipHostMalloc((void**)&c->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&c->d_hctr, c->h_ctr, 0) != hipSuccess || !c->d_hctr ||
             hipGetSymbolAddress(&sp, HIP_SYMBOL(rt_static_scratch)) != hipSuccess || !sp) {
             rt_shutdown(c);
             return RT_ERR_DEVICE;
@@ -1203,6 +1223,7 @@ int rt_init(const int* device_ids, int n_devices, rt_ctx** out) {
         const char* pb = getenv("RT_PERSISTENT_BLOCKS");
         if (pb && atoi(pb) > 0) c->persistent_blocks = atoi(pb);
         if (const char* e = getenv("RT_SPREAD_LANES")) c->spread_lanes = strtoull(e, nullptr, 10);
+        c->no_tail_swap = getenv("RT_NO_TAIL_SWAP") != nullptr;
     }
     *out = c;
     return RT_OK;
