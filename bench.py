@@ -52,6 +52,7 @@ VALU_SLOW_CLASS_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 L1_LANE_ACCESS_PEAK_G = 256 * 1.0 * 2.4e9 / 1e9
 PER_RAY_FILE = os.path.join(ROOT, "profiles", "c5_per_ray.json")
 PMC_FILE = os.path.join(ROOT, "profiles", "c5_k_shadow_pmc.json")
+PMC_C1_FILE = os.path.join(ROOT, "profiles", "c1_k_closest_pmc.json")
 CHECKSUM_FILE = os.path.join(ROOT, "profiles", "c5_checksum.json")   # frame checksums of the plain reference-order traversal
 
 SIDE_CONFIGS = {   # BASELINE configs 1-4: name -> (scene, width, height, spp, max_depth)
@@ -88,6 +89,30 @@ def load_json(path):
         return None
 
 
+def closest_roofline(rays_per_frame, ms_per_frame):
+    """The bounce path's fraction (C1: primaries, reflections, refractions down to depth 50): VALU lane-operations executed by
+    k_closest per ray, from a committed PMC run of this build (tools/pmc_c1.sh -> profiles/c1_k_closest_pmc.json), times the rays of
+    the frame just timed, over k_closest's time in it (HIP events on the library's stream), against the f32 vector peak."""
+    pmc = load_json(PMC_C1_FILE)
+    if not pmc or ms_per_frame <= 0:
+        return None
+    fresh = pmc.get("kernel_source_sha256") is not None and pmc.get("kernel_source_sha256") == kernel_source_hash()
+    r = {"kernel": "k_closest", "bound": "valu", "unit": "Tlane-op/s", "peak": round(VALU_PEAK_TLANEOPS, 3), "pmc_matches_build": bool(fresh),
+         "rays_per_frame": int(rays_per_frame), "kernel_ms_per_frame": round(ms_per_frame, 3)}
+    if not fresh:
+        r.update({"achieved": None, "frac": None, "note": "profiles/c1_k_closest_pmc.json was taken on other kernel sources: rerun tools/pmc_c1.sh + tools/pmc_c1_json.py"})
+        return r
+    achieved = pmc["valu_lane_ops_per_ray"] * rays_per_frame / (ms_per_frame * 1e-3) / 1e12
+    r.update({"achieved": round(achieved, 3), "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
+              "valu_lane_ops_per_ray": round(pmc["valu_lane_ops_per_ray"], 1), "lanes_active_per_valu_inst": round(pmc["lanes_active_per_valu_inst"], 4),
+              "hbm": {"bytes_per_ray": round(pmc["hbm_bytes_per_ray"], 1), "achieved": round(pmc["hbm_bytes_per_ray"] * rays_per_frame / (ms_per_frame * 1e-3) / 1e9, 1),
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+              "launches_per_frame": pmc["launches_per_frame"],
+              "note": "the frame's k_closest time is mostly the latency of its launches on small batches (the depth-50 tail: 45 launches of 1 to 131 k states), not issue or bandwidth",
+              "pmc_source": pmc.get("source")})
+    return r
+
+
 def time_side_config(rt, torch, device, name):
     """ms per frame of one of the 1080p configs on this GPU (1 warm-up frame, 3 timed)."""
     scene_name, W, H, spp, depth = SIDE_CONFIGS[name]
@@ -111,14 +136,22 @@ def time_side_config(rt, torch, device, name):
         t0 = time.perf_counter()
         rays = 0
         k = 3
+        ms_closest = ms_shadow = 0.0
         for _ in range(k):
-            rays += step().rays
+            st = step()
+            rays += st.rays
+            ms_closest += st.ms_closest
+            ms_shadow += st.ms_shadow
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         st = ctx.stats()
-        return {"ms_per_frame": round(el / k * 1e3, 2), "mrays_per_s": round(rays / el / 1e6, 1), "spp": spp, "max_depth": depth,
-                "rays_traced_per_frame": st.rays, "shadow_rays_culled_per_frame": st.rays_shadow_culled,
-                "frame_checksum": float(np.nan_to_num(frame.double().cpu().numpy(), nan=0.0, posinf=0.0, neginf=0.0).sum())}
+        out = {"ms_per_frame": round(el / k * 1e3, 2), "mrays_per_s": round(rays / el / 1e6, 1), "spp": spp, "max_depth": depth,
+               "rays_traced_per_frame": st.rays, "shadow_rays_culled_per_frame": st.rays_shadow_culled,
+               "kernel_ms_per_frame": {"k_shadow": round(ms_shadow / k, 2), "k_closest": round(ms_closest / k, 2)},
+               "frame_checksum": float(np.nan_to_num(frame.double().cpu().numpy(), nan=0.0, posinf=0.0, neginf=0.0).sum())}
+        if name.startswith("C1"):
+            out["roofline_k_closest"] = closest_roofline(st.rays_primary + st.rays_secondary, ms_closest / k)
+        return out
     finally:
         ctx.close()
 

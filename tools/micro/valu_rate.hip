@@ -49,6 +49,14 @@ __global__ void __launch_bounds__(256) k_rate(float* out, int iters, float a, fl
                 if (KIND == 31) asm volatile("v_fma_mix_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
                 if (KIND == 32) asm volatile("v_mov_b32 %0, %1" : "+v"(x[i]) : "v"(a));
                 if (KIND == 33) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[i]) : "v"(a));
+                if (KIND == 34) asm volatile("v_mad_i32_i16 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 35) asm volatile("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 36) asm volatile("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 37) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 38) asm volatile("v_max_i32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+                if (KIND == 39) asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b));
+                if (KIND == 40) asm volatile("v_cmp_le_i32 s[10:11], %0, %1" : : "v"(x[i]), "v"(a) : "s10", "s11");
+                if (KIND == 41) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
             }
         }
     }
@@ -143,6 +151,14 @@ int main() {
         run<31>("v_fma_mix_f32", w, d);
         run<32>("v_mov_b32", w, d);
         run<33>("v_mov_dpp quad", w, d);
+        run<34>("v_mad_i32_i16", w, d);
+        run<35>("mad_i32_i16 hi", w, d);
+        run<36>("mad_u32_u16 hi", w, d);
+        run<37>("v_max3_i32", w, d);
+        run<38>("v_max_i32", w, d);
+        run<39>("v_dot2_i32_i16", w, d);
+        run<40>("v_cmp_le_i32 s", w, d);
+        run<41>("v_sub_u32", w, d);
         run<0, true>("v_pk_fma_f32", w, d);
         run<1, true>("v_pk_mul_f32", w, d);
         run<2, true>("v_pk_add_f32", w, d);
