@@ -147,6 +147,7 @@ def time_side_config(rt, torch, device, name):
         st = ctx.stats()
         out = {"ms_per_frame": round(el / k * 1e3, 2), "mrays_per_s": round(rays / el / 1e6, 1), "spp": spp, "max_depth": depth,
                "rays_traced_per_frame": st.rays, "shadow_rays_culled_per_frame": st.rays_shadow_culled,
+               "shadow_queries_settled_by_group_test_per_frame": st.rays_shadow_grouped,       # answered without a ray of their own; not in rays_traced, not in mrays_per_s
                "kernel_ms_per_frame": {"k_shadow": round(ms_shadow / k, 2), "k_closest": round(ms_closest / k, 2)},
                "frame_checksum": float(np.nan_to_num(frame.double().cpu().numpy(), nan=0.0, posinf=0.0, neginf=0.0).sum())}
         if name.startswith("C1"):

@@ -132,7 +132,7 @@ typedef struct {
 } rt_render_params;
 
 typedef struct {
-    uint64_t rays_primary, rays_secondary, rays_shadow;   /* one ray = one BVH_Node::intersectObjects query */
+    uint64_t rays_primary, rays_secondary, rays_shadow;   /* one ray = one BVH_Node::intersectObjects query (rays_shadow: answered; see rays_shadow_grouped) */
     uint64_t nonfinite;         /* radiance contributions that were NaN/Inf (dropped from the sum) */
     uint64_t iterations;        /* wavefront iterations */
     uint64_t rays_shadow_culled; /* shadow rays NOT traced: their hit's whole Phong term, weighted by the path's throughput, lies below half a
@@ -144,6 +144,10 @@ typedef struct {
     double ms_shadow;           /* sum over launches of the shadow kernel */
     uint64_t launches_closest, launches_shadow;
     uint64_t peak_states;       /* high-water mark of the path-state stack */
+    uint64_t rays_shadow_grouped; /* of rays_shadow: shadow queries answered without a ray of their own -- all 35 rays of a (hit, light) pair
+                                  * stay inside a swept cube from the hit point to the light's sphere that is clear of every object's box, so
+                                  * Scene::isInShadow is false for each of them (k_shadow_group). The answers are the reference's; the rays were
+                                  * not traced: throughput figures count rays_shadow - rays_shadow_grouped. RT_NO_GROUP_CULL=1 traces them all. */
 } rt_stats;
 
 /* One closest-hit result, RayIntersection (Ray.h:13-24) + identity. */

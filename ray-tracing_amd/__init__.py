@@ -98,12 +98,13 @@ class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("nonfinite", C.c_uint64), ("iterations", C.c_uint64), ("rays_shadow_culled", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_closest", C.c_double), ("ms_shadow", C.c_double),
-                ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64), ("peak_states", C.c_uint64)]
+                ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64), ("peak_states", C.c_uint64),
+                ("rays_shadow_grouped", C.c_uint64)]
 
     @property
     def rays(self):
-        """Rays traced (one ray = one BVH_Node::intersectObjects query)."""
-        return self.rays_primary + self.rays_secondary + self.rays_shadow
+        """Rays traced (one ray = one BVH_Node::intersectObjects query); shadow queries settled by the group test are not rays."""
+        return self.rays_primary + self.rays_secondary + self.rays_shadow - self.rays_shadow_grouped
 
     @property
     def shadow_queries(self):

@@ -130,6 +130,17 @@ struct DScene {
     /* per launch: k_closest takes one state per 2^spread_shift lanes (the others stay idle). A small batch of bounced rays is
      * latency-bound, and the lanes of a wave serialise their divergent walks: spread over more waves the batch ends sooner */
     int32_t spread_shift;
+    /* group culling of shadow rays (k_shadow_group): per top-level object ordinal the box every accepted hit on it stays inside
+     * (2 x float4: min.xyz max.x | max.yz kind -; kind 0 square, 1 sphere, 2 mesh; an object that cannot be hit has min = +inf,
+     * one without a bound min = -inf, max = +inf), and the box of admitted ray origins the paddings assume. n_obox = 0: none. */
+    const float4* obox;
+    int32_t n_obox;
+    float gomin[3], gomax[3];
+    /* per launch: the (record, light) pairs whose rays are traced -- pair k of the launch is key group_keys[k] (nullptr: all
+     * n_rec * n_lights pairs in order) */
+    const uint32_t* group_keys;
+    uint32_t group_n;
+    int32_t group_debug;        /* RT_DEBUG: k_shadow_group counts why pairs stay (Counters::group_why) */
 };
 /* head of section 6 of top_blob, in front of tsub */
 struct TopFrame {

@@ -43,6 +43,8 @@ struct Counters {
     unsigned long long deferred;    /* rays k_shadow_front handed to the running k_shadow launch */
     unsigned long long deferred_sum; /* ... to all launches of this frame */
     unsigned long long culled;       /* diffuse hits k_closest dropped because they cannot change the frame (contribution culling) */
+    unsigned long long n_keys;       /* (record, light) pairs k_shadow_group left for the running launch */
+    unsigned long long group_why[4]; /* RT_DEBUG: pairs kept because of their origin or length / a square / a sphere / a mesh */
     unsigned long long sh_node_steps, sh_tri_steps, sh_other_steps, sh_loop_iters;   /* RT_COUNT=1 diagnostics */
     unsigned long long sh_node_iters, sh_tri_iters, sh_top_iters, sh_top_lanes;
     unsigned long long sh_m1_node, sh_m1_tri, sh_m1_rays;   /* steps taken and rays finished in mode 1 (the second walk of shadow_walk) */
@@ -1394,8 +1396,11 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
     if (link == LINK_NONE) {                                         /* the one place where the walk pops */
         if (s.msp == sc.top_cap) { s.st = ST_TOP; return; }        /* mesh done without a hit: next object of the leaf */
         --s.msp;
-        if (s.msp < w.lds_cap) link = w.lds[s.msp * RT_BLOCK];
-        else { asm volatile("" ::: "memory"); link = w.ovf[(s.msp - w.lds_cap) * RT_BLOCK]; }   /* (kept a branch: a select of the two addresses becomes a flat load) */
+        /* the LDS read is unconditional (of a clamped slot) and the spilled entry a separate, rare load: as the two arms of one
+         * branch the compiler merges them into a select of the two addresses and a flat load, which costs a 64-bit address, both
+         * memory pipes and both wait counters on every pop */
+        link = w.lds[(s.msp < w.lds_cap ? s.msp : w.lds_cap - 1) * RT_BLOCK];
+        if (s.msp >= w.lds_cap) link = w.ovf[(s.msp - w.lds_cap) * RT_BLOCK];
     }
     if (TOPSUB && link == LINK_SENTINEL) {
         /* the mesh entered from the sub-tree of a top-level leaf is done: back to the scene's frame -- once the mesh's
@@ -1544,6 +1549,7 @@ RT_DEV void shadow_ray_of(const DScene& sc, const FrameD& fr, const DiffuseRec* 
         key = (uint32_t)(idx / (unsigned)S);
         i = (uint32_t)(idx % (unsigned)S);
     }
+    if (sc.group_keys) key = sc.group_keys[key];      /* (the launch holds the pairs k_shadow_group left, in its order) */
     uint32_t rec = key, li = 0u;
     if (sc.n_lights != 1) { rec = key / (uint32_t)sc.n_lights; li = key - rec * (uint32_t)sc.n_lights; }
     const float4* q = reinterpret_cast<const float4*>(drec + rec);
@@ -1579,11 +1585,127 @@ __global__ void __launch_bounds__(256) k_hash_records(uint32_t seed, const Diffu
     const float4 q3 = reinterpret_cast<const float4*>(drec + rec)[3];
     dcode[rec] = (unsigned long long)rt_rng_prefix(seed, __float_as_uint(q3.z), __float_as_uint(q3.w), dcode[rec]);
 }
+/* ---- group culling of shadow rays. The 35 shadow rays of a (diffuse record, light) pair all start within 0.001 of the hit
+ * point P and end within 0.001 of the light's sphere (centre C, radius R): every point o + t d, 0 <= t <= lightDistance, of
+ * every one of them lies in the swept cube {P + s (C - P) +- h(s)}, s in [0, 1], h(s) = h0 + s (h1 - h0), h0 = 0.002 + slack,
+ * h1 = R (1 + 1e-5) + 0.002 + slack. Every hit an object's test accepts lies in the object's box (DScene::obox: the boxes of
+ * the sub-trees over top-level objects, rtgpu.hip), so a box the swept cube stays clear of cannot yield a hit at
+ * t <= lightDistance on any of the 35 rays; a square is also out when all 35 rays travel along its normal (Square.h:74 returns
+ * before anything else); a sphere's tangent root may be negative (Sphere.h:113), so its box must be clear of the rays' lines
+ * behind P as well. When every object of the scene is out, Scene::isInShadow is false for all 35 rays -- no object returns a
+ * result at t <= lightDistance, so no leaf of BVH_Node::intersectObjects does, whatever their order (AccelerationStruct.cpp:
+ * 293-311,326-330) -- and the pair's shadow count is the 0 its counter was cleared to: its rays are not made. Everything is
+ * decided by comparisons that are false on NaN; a pair is dropped only on proof. */
+RT_DEV bool hull_clear_of_box(F3 A, F3 D, float h0, float dh, float smin, float smax, float hs, float4 b0, float4 b1) {
+    const float mn[3] = {b0.x, b0.y, b0.z}, mx[3] = {b0.w, b1.x, b1.y};
+    const float a3[3] = {A.x, A.y, A.z}, d3[3] = {D.x, D.y, D.z};
+    float lo = smin, hi = smax;
+    bool empty = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        /* the cube's upper face reaches the box's lower one: s (D_k + hs dh) >= mn_k - A_k - h0 */
+        {
+            const float a = d3[k] + hs * dh, b = mn[k] - a3[k] - h0;
+            const float q = b / a, m = 1e-5f * (1.0f + fabsf(q));
+            if (a > 0.f) lo = fmaxf(lo, q - m);
+            else if (a < 0.f) hi = fminf(hi, q + m);
+            else if (a == 0.f && b > 0.f) empty = true;
+        }
+        /* its lower face stays below the box's upper one: s (D_k - hs dh) <= mx_k - A_k + h0 */
+        {
+            const float a = d3[k] - hs * dh, b = mx[k] - a3[k] + h0;
+            const float q = b / a, m = 1e-5f * (1.0f + fabsf(q));
+            if (a > 0.f) hi = fminf(hi, q + m);
+            else if (a < 0.f) lo = fmaxf(lo, q - m);
+            else if (a == 0.f && b < 0.f) empty = true;
+        }
+    }
+    return empty || lo > hi;
+}
+__global__ void __launch_bounds__(256) k_shadow_group(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec, uint32_t n_rec,
+                                                      uint32_t* __restrict__ keys, Counters* ctr) {
+    __shared__ uint32_t s_tot[6];
+    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_pairs = n_rec * (uint32_t)sc.n_lights;
+    bool keep = key < n_pairs;
+    int why_out = -1;
+    if (keep) {
+        uint32_t rec = key, li = 0u;
+        if (sc.n_lights != 1) { rec = key / (uint32_t)sc.n_lights; li = key - rec * (uint32_t)sc.n_lights; }
+        const float4 q0 = reinterpret_cast<const float4*>(drec + rec)[0];
+        const F3 P = f3(q0.x, q0.y, q0.z);
+        const DLight L = sc.lights[li];
+        const F3 C = f3(L.pos[0], L.pos[1], L.pos[2]);
+        const float R = fr.shadow_mode == 0 ? fabsf(L.radius) : 0.f;
+        const F3 D = sub(C, P);
+        const float dist = len(D);
+        const float big = fmaxf(fmaxf(fabsf(P.x), fabsf(P.y)), fmaxf(fabsf(P.z), fmaxf(fmaxf(fabsf(C.x), fabsf(C.y)), fabsf(C.z)))) + R;
+        const float slack = 64.f * 5.9604645e-8f * (big + dist);              /* the float arithmetic of the sample position, the origin and the hit point */
+        const float h0 = 0.002f + slack, h1 = R * 1.00001f + 0.002f + slack, dh = h1 - h0;
+        /* origins the object boxes' paddings were derived for (the light may lie outside: what the paddings bound is the rounding of a hit
+         * point, which grows with its distance from the origin, and a hit lies in an object's box, within the scene), a ray with a length */
+        bool clear = P.x >= sc.gomin[0] && P.x <= sc.gomax[0] && P.y >= sc.gomin[1] && P.y <= sc.gomax[1] && P.z >= sc.gomin[2] && P.z <= sc.gomax[2] &&
+                     dist > 4.f * h1 && dist < 1e15f && big < 1e15f;
+        /* how far back the rays' lines can matter (spheres): the admitted box's diagonal, in units of |C - P| */
+        const float back = clear ? (fabsf(sc.gomax[0] - sc.gomin[0]) + fabsf(sc.gomax[1] - sc.gomin[1]) + fabsf(sc.gomax[2] - sc.gomin[2])) / dist : 0.f;
+        int why = clear ? -1 : 0;
+        for (int o = 0; o < sc.n_obox && clear; o++) {
+            float4 b0 = sc.obox[2 * o], b1 = sc.obox[2 * o + 1];
+            const int kind = __float_as_int(b1.z);
+            if (kind == 1) {
+                /* a sphere's uploaded box is padded for the farthest admitted origin (the rounding of a root grows with the square of the
+                 * origin's distance: | |hit - centre|^2 - r^2 | <= 96 u (|o - centre| + r)^2, rtgpu.hip) -- a scene with a large floor makes
+                 * that metres. This pair's origins are within 0.002 of P: the same bound with their distance */
+                const float4 sp = sc.spheres[2 * (o - sc.n_squares)];
+                const float r = sp.w, oc = len(sub(P, f3(sp.x, sp.y, sp.z))) + 0.002f;
+                const float pad = 96.f * 5.9604645e-8f * (oc + r) * (oc + r) / r + 1e-5f * r + slack + 1e-6f;
+                if (r > 0.f && pad < 1e15f && b0.x <= b0.w) {
+                    b0 = make_float4(sp.x - r - pad, sp.y - r - pad, sp.z - r - pad, sp.x + r + pad);
+                    b1 = make_float4(sp.y + r + pad, sp.z + r + pad, b1.z, 0.f);
+                }
+            }
+            bool out = hull_clear_of_box(P, D, h0, dh, 0.f, 1.f, 1.f, b0, b1);
+            if (kind == 1) out = out && hull_clear_of_box(P, D, h0, dh, -back, 0.f, -1.f, b0, b1);
+            if (kind == 0 && !out) {
+                /* every ray has dot(d, n) > 0: (lp - P).n >= (C - P).n - R |n|, with a margin far above the rounding of the dot */
+                const float4 q3 = sc.squares[4 * o + 3];
+                const F3 n = f3(q3.x, q3.y, q3.z);
+                const float nl = len(n);
+                out = dot(D, n) > (R * 1.001f + 1e-4f * (dist + R)) * nl && nl > 0.f;
+            }
+            clear = out;
+            if (!out) why = 1 + kind;
+        }
+        keep = !clear;
+        if (!keep) why = -1;
+        why_out = why;
+    }
+    if (sc.group_debug) {                         /* one atomic per wave and reason */
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long m = __ballot(why_out == k);
+            if (m && __lane_id() == 0) atomicAdd(&ctr->group_why[k], (unsigned long long)__popcll(m));
+        }
+    }
+    /* block-aggregated append of the pairs that stay */
+    const unsigned long long km = __ballot(keep);
+    const int lane = __lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (lane == 0) s_tot[wave] = (uint32_t)__popcll(km);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (int w = 0; w < 4; w++) { const uint32_t a = s_tot[w]; s_tot[w] = sum; sum += a; }
+        s_tot[4] = sum ? (uint32_t)atomicAdd(&ctr->n_keys, (unsigned long long)sum) : 0u;
+    }
+    __syncthreads();
+    if (keep) keys[s_tot[4] + s_tot[wave] + (uint32_t)__popcll(km & lt)] = key;
+}
+
 __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
                                                       const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
                                                       float4* __restrict__ rays) {
     unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    const unsigned long long total = sc.group_keys ? (unsigned long long)sc.group_n * S : (unsigned long long)n_rec * sc.n_lights * S;
     if (idx >= total) return;
     uint32_t key; F3 o, d; float lightDistance;
     shadow_ray_of(sc, fr, drec, dcode, idx, S, key, o, d, lightDistance);
@@ -1600,7 +1722,7 @@ __global__ void __launch_bounds__(256) k_shadow_direct(DScene sc, FrameD fr, con
                                                        const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S, uint32_t* cnt) {
     extern __shared__ __align__(16) int s_stack[];
     unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    const unsigned long long total = sc.group_keys ? (unsigned long long)sc.group_n * S : (unsigned long long)n_rec * sc.n_lights * S;
     const bool active = idx < total;
     uint32_t key = 0xFFFFFFFFu;
     bool occ = false;
@@ -1636,7 +1758,7 @@ __global__ void __launch_bounds__(RT_FBLOCK) k_shadow_front(DScene sc, FrameD fr
     extern __shared__ __align__(16) int s_stack[];
     uint32_t* s_tot = reinterpret_cast<uint32_t*>(s_stack + (size_t)sc.top_cap * blockDim.x);
     unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long total = (unsigned long long)n_rec * sc.n_lights * S;
+    const unsigned long long total = sc.group_keys ? (unsigned long long)sc.group_n * S : (unsigned long long)n_rec * sc.n_lights * S;
     const bool active = idx < total;
     uint32_t key = 0xFFFFFFFFu;
     bool occ = false, defer = false;

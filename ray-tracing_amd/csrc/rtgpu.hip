@@ -73,7 +73,7 @@ struct rt_ctx {
     unsigned long long queued_samples = 0;
     int32_t resolve_spp = 0;        /* sample-sharded frames (rt_begin_frame_samples): the frame's samples per pixel over ALL contexts, what a resolve divides by; 0 = this context's own count */
 
-    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, ctr, tilebuf, srays, dtex, ovf;
+    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, keys, ctr, tilebuf, srays, dtex, ovf;
     uint32_t batch = 32u << 20;   /* path states per wavefront iteration at most (RT_BATCH). One batch of diffuse hits is one launch of the persistent shadow kernel, and
                                    * every launch ends in a tail of a few ms in which the longest rays finish alone: measured on C5 at 1 / 4 / 8 / 16 / 32 Mi states
                                    * 1112 / 1244 / 1334 / 1340 / 1358 Mrays/s (gorilla 75.6 / 65.8 / 61.8 ms per frame with 1 / 4 / 16 Mi). What a batch really
@@ -81,6 +81,8 @@ struct rt_ctx {
     unsigned long long mem_budget = 96ull << 30;    /* bytes the buffers of the wavefront loop may take together (RT_MEM_BUDGET_GB; HBM is 288 GB) */
     bool debug = false, count_steps = false;
     int persistent_blocks = 256 * 16;
+    int group_state = -1;                          /* group culling of shadow rays on this scene: -1 undecided (runs, and counts), 0 off, 1 on */
+    unsigned long long group_seen = 0, group_kept = 0, group_min_pairs = 8192;
     bool no_tail_swap = false;                     /* RT_NO_TAIL_SWAP (test knob): the children of every iteration are copied onto the stack */
     unsigned long long spread_lanes = 131072;      /* run_wavefront: lanes a small batch of bounced rays is spread over (RT_SPREAD_LANES, 0 = one state per lane always) */
     int wide_mode = 2;              /* closest hits over the 4-wide quantised tree: 0 never, 1 always, 2 for batches of bounced rays and rt_intersect (RT_WIDE_CLOSEST=0|1 overrides; see run_wavefront) */
@@ -235,6 +237,7 @@ struct WaveBufs {
     PathState* child;                       /* 2 * batch */
     DiffuseRec* drec; unsigned long long* dcode; uint32_t* dtex;   /* batch each */
     uint32_t* cnt;                          /* batch * lights */
+    uint32_t* keys;                         /* batch * lights: the (record, light) pairs k_shadow_group leaves; nullptr = no group culling */
     Counters* ctr;
     TileD* tilebuf;                         /* from_tiles only */
     float4* srays; unsigned long long srays_cap;    /* shadow-ray buffer, capacity in rays (2 float4 each) */
@@ -263,7 +266,7 @@ int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
      * counters, and the shadow rays of its hit (32 bytes each, unless the scene has no meshes: no ray buffer then) */
     const bool no_ray_buffer = (c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW")) || L == 0;
     const unsigned long long per_state = (unsigned long long)sizeof(PathState) * (unsigned long long)(src.max_depth + 3 + 2) + sizeof(DiffuseRec) + 12ull +
-                                         4ull * (unsigned long long)std::max(L, 1) + (no_ray_buffer ? 0ull : 32ull * (unsigned long long)std::max(L, 1) * (unsigned long long)S);
+                                         8ull * (unsigned long long)std::max(L, 1) + (no_ray_buffer ? 0ull : 32ull * (unsigned long long)std::max(L, 1) * (unsigned long long)S);
     const unsigned long long affordable = std::max<unsigned long long>(1ull << 20, (c->mem_budget / per_state) & ~1023ull);
     const uint32_t B = (uint32_t)std::min<unsigned long long>(std::min<unsigned long long>(c->batch, affordable), (std::max<unsigned long long>(src.total, 4096ull) + 1023ull) & ~1023ull);
     size_t need_stack = (size_t)B * (size_t)(src.max_depth + 3);
@@ -274,6 +277,7 @@ int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
     if ((rc = ensure(c, c->dcode, (size_t)B * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(c, c->dtex, (size_t)B * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->cnt, (size_t)B * std::max(L, 1) * sizeof(uint32_t)))) return rc;
+    if (c->sc.n_obox > 0 && (rc = ensure(c, c->keys, (size_t)B * std::max(L, 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->ctr, sizeof(Counters)))) return rc;
     if (src.from_tiles && (rc = ensure(c, c->tilebuf, std::max<size_t>(c->tiles.size(), 1) * sizeof(TileD)))) return rc;
     const unsigned long long per_rec = (unsigned long long)std::max(L, 1) * S;
@@ -288,6 +292,7 @@ int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
     w.child = static_cast<PathState*>(c->child.p);
     w.drec = static_cast<DiffuseRec*>(c->drec.p); w.dcode = static_cast<unsigned long long*>(c->dcode.p); w.dtex = static_cast<uint32_t*>(c->dtex.p);
     w.cnt = static_cast<uint32_t*>(c->cnt.p); w.ctr = static_cast<Counters*>(c->ctr.p);
+    w.keys = c->sc.n_obox > 0 ? static_cast<uint32_t*>(c->keys.p) : nullptr;
     w.tilebuf = static_cast<TileD*>(c->tilebuf.p);
     w.srays = static_cast<float4*>(c->srays.p); w.srays_cap = c->srays.bytes / (2 * sizeof(float4));
     w.ovf = static_cast<int*>(c->ovf.p); w.ovf_bytes = c->ovf.bytes;
@@ -424,6 +429,36 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count());
         if (n_child > 2 * B || n_diff > B) return fail(c, RT_ERR_LIMIT, "queue overflow (%u children, %u diffuse)", n_child, n_diff);
         /* 3. shadow + Phong for the diffuse records of this batch */
+        /* Group culling (k_shadow_group, rt_kernels.h): the (record, light) pairs of a chunk whose 35 rays provably meet nothing are
+         * dropped before any ray is made; the launches below then run over the pairs that are left. One more read-back per chunk, so
+         * only for chunks worth it; the first million pairs of a scene decide whether the scene's objects leave enough pairs clear
+         * to pay for the test (its cost grows with the number of objects). */
+        auto group_pass = [&](uint32_t r0, uint32_t nr, DScene& scs, unsigned long long& threads) -> int {
+            scs.group_keys = nullptr; scs.group_n = 0;
+            const unsigned long long pairs = (unsigned long long)nr * (unsigned long long)L;
+            if (!w.keys || c->sc.n_obox == 0 || c->group_state == 0 || pairs < c->group_min_pairs || pairs > 0xFFFFFF00ull) return RT_OK;
+            HIP_TRY(c, hipMemsetAsync(&d_ctr->n_keys, 0, sizeof(unsigned long long), c->stream));
+            DScene scq = c->sc;
+            scq.group_debug = c->debug ? 1 : 0;
+            hipLaunchKernelGGL(k_shadow_group, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, c->stream, scq, c->fr, w.drec + r0, nr, w.keys, d_ctr);
+            HIP_TRY(c, hipMemcpyAsync(&c->h_ctr->n_keys, &d_ctr->n_keys, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const unsigned long long kept = c->h_ctr->n_keys;
+            if (kept > pairs) return fail(c, RT_ERR_DEVICE, "group culling returned %llu of %llu pairs", kept, pairs);
+            c->stats.rays_shadow_grouped += (pairs - kept) * (unsigned long long)S;
+            if (c->group_state < 0) {
+                c->group_seen += pairs; c->group_kept += kept;
+                if (c->group_seen >= (1ull << 20)) {
+                    const double clear = 1.0 - (double)c->group_kept / (double)c->group_seen;
+                    c->group_state = clear > 0.02 + 0.004 * (double)c->sc.n_obox ? 1 : 0;
+                    if (c->debug) fprintf(stderr, "[rtgpu] group culling: %.1f %% of %llu (record, light) pairs clear of all %d objects -> %s for this scene\n", 100.0 * clear,
+                                          c->group_seen, c->sc.n_obox, c->group_state ? "on" : "off");
+                }
+            }
+            scs.group_keys = w.keys; scs.group_n = (uint32_t)kept;
+            threads = kept * (unsigned long long)S;
+            return RT_OK;
+        };
         if (n_diff && L > 0) {
             HIP_TRY(c, hipMemsetAsync(w.cnt, 0, (size_t)n_diff * L * sizeof(uint32_t), c->stream));
             const unsigned long long per_rec = (unsigned long long)L * S;
@@ -435,16 +470,19 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                 const uint32_t dchunk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(n_diff, (1ull << 38) / per_rec));
                 for (uint32_t r0 = 0; r0 < n_diff; r0 += dchunk) {
                     const uint32_t nr = std::min(dchunk, n_diff - r0);
-                    const unsigned long long threads = (unsigned long long)nr * per_rec;
+                    unsigned long long threads = (unsigned long long)nr * per_rec;
+                    c->stats.rays_shadow += threads;
+                    DScene scs = c->sc;
+                    if (int grc = group_pass(r0, nr, scs, threads)) return grc;
+                    if (threads == 0) continue;
                     EventPair* e2 = nullptr;
                     if (w.timing) {
                         if (!(e2 = next_event(c, 1))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
                         HIP_TRY(c, hipEventRecord(e2->a, c->stream));
                     }
                     hipLaunchKernelGGL(k_shadow_direct, dim3((uint32_t)((threads + 255) / 256)), dim3(256), (size_t)c->sc.stack_cap * 256 * sizeof(int), c->stream,
-                                       c->sc, c->fr, w.drec + r0, w.dcode + r0, nr, S, w.cnt + (size_t)r0 * L);
+                                       scs, c->fr, w.drec + r0, w.dcode + r0, nr, S, w.cnt + (size_t)r0 * L);
                     if (e2) HIP_TRY(c, hipEventRecord(e2->b, c->stream));
-                    c->stats.rays_shadow += threads;
                 }
             }
             /* the records are processed in chunks that fit the 32-byte ray buffer */
@@ -452,13 +490,16 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
             const uint32_t chunk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(n_diff, w.srays_cap / per_rec));
             for (uint32_t r0 = 0; r0 < n_diff && !direct; r0 += chunk) {
                 const uint32_t nr = std::min(chunk, n_diff - r0);
-                const unsigned long long threads = (unsigned long long)nr * per_rec;
+                unsigned long long threads = (unsigned long long)nr * per_rec;
+                c->stats.rays_shadow += threads;
+                DScene scg = c->sc;
+                if (int grc = group_pass(r0, nr, scg, threads)) return grc;
+                if (threads == 0) continue;
                 /* persistent waves: enough 64-lane blocks to fill the chip, never more than the work */
                 const unsigned long long blocks = std::min<unsigned long long>((threads + RT_BLOCK - 1) / RT_BLOCK, (unsigned long long)w.persistent_blocks);
                 unsigned long long blocks_now = blocks;
                 HIP_TRY(c, hipMemsetAsync(&d_ctr->work, 0, sizeof(unsigned long long), c->stream));
                 uint32_t* cnt0 = w.cnt + (size_t)r0 * L;
-                c->stats.rays_shadow += threads;
                 /* Front pass: rays that stay clear of every mesh frame are settled one thread per ray, the rest go to the
                  * persistent kernel. Whether that pays is the scene's matter (a gorilla on a floor: most rays pass it by;
                  * C5's soup fills the scene: every ray enters it), so the first launch on a scene looks at the share of
@@ -473,12 +514,12 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                         HIP_TRY(c, hipEventRecord(e2->a, c->stream));
                     }
                     hipLaunchKernelGGL(k_shadow_front, dim3((uint32_t)((threads + RT_FBLOCK - 1) / RT_FBLOCK)), dim3(RT_FBLOCK),
-                                       front_lds, c->stream, c->sc, c->fr,
+                                       front_lds, c->stream, scg, c->fr,
                                        w.drec + r0, w.dcode + r0, nr, S, cnt0, w.srays, &d_ctr->deferred, &d_ctr->deferred_sum);
                     blocks_now = (unsigned long long)w.persistent_blocks;      /* (how many rays come through is on the device) */
                     front_rays += threads;
                 } else {
-                    hipLaunchKernelGGL(k_shadow_setup, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->sc, c->fr,
+                    hipLaunchKernelGGL(k_shadow_setup, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, scg, c->fr,
                                        w.drec + r0, w.dcode + r0, nr, S, w.srays);
                     if (w.timing) {
                         if (!(e2 = next_event(c, 1))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
@@ -538,6 +579,9 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->stats.nonfinite += c->h_ctr->nonfinite;
+    if (c->debug && c->sc.n_obox > 0 && c->group_state != 0)
+        fprintf(stderr, "[rtgpu] group culling kept pairs because of: origin or length %llu, a square %llu, a sphere %llu, a mesh %llu\n",
+                c->h_ctr->group_why[0], c->h_ctr->group_why[1], c->h_ctr->group_why[2], c->h_ctr->group_why[3]);
     c->stats.rays_shadow_culled += c->h_ctr->culled * (unsigned long long)L * (unsigned long long)S;
     if (c->count_steps)
         fprintf(stderr, "[rtgpu] shadow steps: node %llu tri %llu other %llu lane-iterations %llu rays %llu; wave iterations: node %llu tri %llu top %llu (top lanes %llu)\n",
@@ -1611,73 +1655,78 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     float top_omin[3] = {0.f, 0.f, 0.f}, top_omax[3] = {0.f, 0.f, 0.f};
     int max_top_sub_depth = 0;
     bool has_topsub = false;
-    if (quant_ok && !getenv("RT_NO_TOP_SPLIT") && d->n_top_items > 0) {
-        const int n_obj = d->n_squares + d->n_spheres + d->n_meshes;
-        /* the scene's extent (object boxes without padding) bounds where shadow rays start: origins further out than one
-         * diagonal take the plain item scan (checked per ray in the kernel) */
-        double emin[3] = {INFINITY, INFINITY, INFINITY}, emax[3] = {-INFINITY, -INFINITY, -INFINITY};
-        auto grow = [&](const double* lo, const double* hi) { for (int k = 0; k < 3; k++) { emin[k] = std::min(emin[k], lo[k]); emax[k] = std::max(emax[k], hi[k]); } };
-        bool finite = true;
-        for (int i = 0; i < d->n_squares && finite; i++) {
+    /* ---- conservative box per top-level object (what every accepted hit on it stays inside): for the sub-trees inside top-level
+     * leaves below, and for the group culling of shadow rays (k_shadow_group) */
+    const int n_obj = d->n_squares + d->n_spheres + d->n_meshes;
+    /* the scene's extent (object boxes without padding) bounds where shadow rays start: origins further out than one
+     * diagonal take the plain item scan (checked per ray in the kernel) */
+    double emin[3] = {INFINITY, INFINITY, INFINITY}, emax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto grow = [&](const double* lo, const double* hi) { for (int k = 0; k < 3; k++) { emin[k] = std::min(emin[k], lo[k]); emax[k] = std::max(emax[k], hi[k]); } };
+    bool finite = true;
+    for (int i = 0; i < d->n_squares && finite; i++) {
+        const rt_square& q = d->squares[i];
+        double lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+            const double v4 = (double)q.v1[k] + (double)q.v3[k] - (double)q.v0[k];
+            lo[k] = std::min(std::min((double)q.v0[k], (double)q.v1[k]), std::min((double)q.v3[k], v4));
+            hi[k] = std::max(std::max((double)q.v0[k], (double)q.v1[k]), std::max((double)q.v3[k], v4));
+            if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false;
+        }
+        if (finite) grow(lo, hi);
+    }
+    for (int i = 0; i < d->n_spheres && finite; i++) {
+        const rt_sphere& sp = d->spheres[i];
+        double lo[3], hi[3];
+        if (!(sp.radius > 0.f) || !(sp.radius < 1e15f)) { finite = false; break; }
+        for (int k = 0; k < 3; k++) { lo[k] = (double)sp.center[k] - sp.radius; hi[k] = (double)sp.center[k] + sp.radius; if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false; }
+        if (finite) grow(lo, hi);
+    }
+    for (int mi = 0; mi < d->n_meshes && finite; mi++) {
+        const HitBox& hb = mesh_hit[(size_t)mi];
+        if (hb.unbounded) { finite = false; break; }
+        if (!(hb.mn[0] <= hb.mx[0])) continue;            /* a mesh that cannot be hit */
+        double lo[3], hi[3];
+        for (int k = 0; k < 3; k++) { lo[k] = hb.mn[k]; hi[k] = hb.mx[k]; if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false; }
+        if (finite) grow(lo, hi);
+    }
+    const double diag = finite && emin[0] <= emax[0] ? std::sqrt((emax[0] - emin[0]) * (emax[0] - emin[0]) + (emax[1] - emin[1]) * (emax[1] - emin[1]) + (emax[2] - emin[2]) * (emax[2] - emin[2])) : 0.0;
+    const bool obox_ok = finite && diag > 0.0 && diag < 1e12;
+    /* conservative box per object ordinal */
+    std::vector<HitBox> obox((size_t)n_obj);
+    double amax_scene = 0.0, Dmax = 0.0;
+    const double u = 1.0 / 16777216.0;
+    if (obox_ok) {
+        for (int k = 0; k < 3; k++) amax_scene = std::max(amax_scene, std::max(std::fabs(emin[k] - diag), std::fabs(emax[k] + diag)));
+        Dmax = 2.5 * diag;            /* largest distance between an admitted origin and a point of the scene */
+        for (int i = 0; i < d->n_squares; i++) {
+            /* Square::intersect accepts P = o + t*d (t > 0) whose u, v computed FROM P lie in [0, 1] (Square.h:81-89): P is
+             * inside the quad up to the rounding of those dot products and off its plane by the rounding of t */
             const rt_square& q = d->squares[i];
-            double lo[3], hi[3];
+            HitBox& b = obox[(size_t)i];
+            double ext = 0.0;
+            for (int k = 0; k < 3; k++) ext = std::max(ext, std::max(std::fabs((double)q.v1[k] - q.v0[k]), std::fabs((double)q.v3[k] - q.v0[k])));
+            const float pad = (float)(1e-4 * ext + 64.0 * u * (amax_scene + Dmax) + 1e-6);
             for (int k = 0; k < 3; k++) {
-                const double v4 = (double)q.v1[k] + (double)q.v3[k] - (double)q.v0[k];
-                lo[k] = std::min(std::min((double)q.v0[k], (double)q.v1[k]), std::min((double)q.v3[k], v4));
-                hi[k] = std::max(std::max((double)q.v0[k], (double)q.v1[k]), std::max((double)q.v3[k], v4));
-                if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false;
+                const float v4 = q.v1[k] + q.v3[k] - q.v0[k];
+                b.mn[k] = std::min(std::min(q.v0[k], q.v1[k]), std::min(q.v3[k], v4)) - pad;
+                b.mx[k] = std::max(std::max(q.v0[k], q.v1[k]), std::max(q.v3[k], v4)) + pad;
             }
-            if (finite) grow(lo, hi);
         }
-        for (int i = 0; i < d->n_spheres && finite; i++) {
+        for (int i = 0; i < d->n_spheres; i++) {
+            /* Sphere::intersect (Sphere.h:86-146) accepts P = o + t*d for a float root t of a*t^2 + b*t + c: with the
+             * coefficients and the root rounded, | |P - centre|^2 - r^2 | <= 96 u (|o - centre| + r)^2, hence P lies within
+             * 96 u (D + r)^2 / r of the sphere (D: the largest admitted distance of an origin). The root may be NEGATIVE
+             * (discriminant exactly 0, Sphere.h:113): nodes holding a sphere are tested against the ray's whole line (WIDE_LINE). */
             const rt_sphere& sp = d->spheres[i];
-            double lo[3], hi[3];
-            if (!(sp.radius > 0.f) || !(sp.radius < 1e15f)) { finite = false; break; }
-            for (int k = 0; k < 3; k++) { lo[k] = (double)sp.center[k] - sp.radius; hi[k] = (double)sp.center[k] + sp.radius; if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false; }
-            if (finite) grow(lo, hi);
+            HitBox& b = obox[(size_t)(d->n_squares + i)];
+            const double r = sp.radius;
+            const float pad = (float)(96.0 * u * (Dmax + r) * (Dmax + r) / r + 1e-5 * r + 64.0 * u * (amax_scene + Dmax) + 1e-6);
+            for (int k = 0; k < 3; k++) { b.mn[k] = sp.center[k] - sp.radius - pad; b.mx[k] = sp.center[k] + sp.radius + pad; }
         }
-        for (int mi = 0; mi < d->n_meshes && finite; mi++) {
-            const HitBox& hb = mesh_hit[(size_t)mi];
-            if (hb.unbounded) { finite = false; break; }
-            if (!(hb.mn[0] <= hb.mx[0])) continue;            /* a mesh that cannot be hit */
-            double lo[3], hi[3];
-            for (int k = 0; k < 3; k++) { lo[k] = hb.mn[k]; hi[k] = hb.mx[k]; if (!(std::fabs(lo[k]) < 1e15) || !(std::fabs(hi[k]) < 1e15)) finite = false; }
-            if (finite) grow(lo, hi);
-        }
-        const double diag = finite && emin[0] <= emax[0] ? std::sqrt((emax[0] - emin[0]) * (emax[0] - emin[0]) + (emax[1] - emin[1]) * (emax[1] - emin[1]) + (emax[2] - emin[2]) * (emax[2] - emin[2])) : 0.0;
-        if (finite && diag > 0.0 && diag < 1e12) {
-            /* conservative box per object ordinal */
-            std::vector<HitBox> obox((size_t)n_obj);
-            const double u = 1.0 / 16777216.0;
-            double amax_scene = 0.0;
-            for (int k = 0; k < 3; k++) amax_scene = std::max(amax_scene, std::max(std::fabs(emin[k] - diag), std::fabs(emax[k] + diag)));
-            const double Dmax = 2.5 * diag;            /* largest distance between an admitted origin and a point of the scene */
-            for (int i = 0; i < d->n_squares; i++) {
-                /* Square::intersect accepts P = o + t*d (t > 0) whose u, v computed FROM P lie in [0, 1] (Square.h:81-89): P is
-                 * inside the quad up to the rounding of those dot products and off its plane by the rounding of t */
-                const rt_square& q = d->squares[i];
-                HitBox& b = obox[(size_t)i];
-                double ext = 0.0;
-                for (int k = 0; k < 3; k++) ext = std::max(ext, std::max(std::fabs((double)q.v1[k] - q.v0[k]), std::fabs((double)q.v3[k] - q.v0[k])));
-                const float pad = (float)(1e-4 * ext + 64.0 * u * (amax_scene + Dmax) + 1e-6);
-                for (int k = 0; k < 3; k++) {
-                    const float v4 = q.v1[k] + q.v3[k] - q.v0[k];
-                    b.mn[k] = std::min(std::min(q.v0[k], q.v1[k]), std::min(q.v3[k], v4)) - pad;
-                    b.mx[k] = std::max(std::max(q.v0[k], q.v1[k]), std::max(q.v3[k], v4)) + pad;
-                }
-            }
-            for (int i = 0; i < d->n_spheres; i++) {
-                /* Sphere::intersect (Sphere.h:86-146) accepts P = o + t*d for a float root t of a*t^2 + b*t + c: with the
-                 * coefficients and the root rounded, | |P - centre|^2 - r^2 | <= 96 u (|o - centre| + r)^2, hence P lies within
-                 * 96 u (D + r)^2 / r of the sphere (D: the largest admitted distance of an origin). The root may be NEGATIVE
-                 * (discriminant exactly 0, Sphere.h:113): nodes holding a sphere are tested against the ray's whole line (WIDE_LINE). */
-                const rt_sphere& sp = d->spheres[i];
-                HitBox& b = obox[(size_t)(d->n_squares + i)];
-                const double r = sp.radius;
-                const float pad = (float)(96.0 * u * (Dmax + r) * (Dmax + r) / r + 1e-5 * r + 64.0 * u * (amax_scene + Dmax) + 1e-6);
-                for (int k = 0; k < 3; k++) { b.mn[k] = sp.center[k] - sp.radius - pad; b.mx[k] = sp.center[k] + sp.radius + pad; }
-            }
-            for (int mi = 0; mi < d->n_meshes; mi++) obox[(size_t)(d->n_squares + d->n_spheres + mi)] = mesh_hit[(size_t)mi];
+        for (int mi = 0; mi < d->n_meshes; mi++) obox[(size_t)(d->n_squares + d->n_spheres + mi)] = mesh_hit[(size_t)mi];
+    }
+    if (quant_ok && !getenv("RT_NO_TOP_SPLIT") && d->n_top_items > 0) {
+        if (obox_ok) {
             /* frame of the 16-bit planes: everything the boxes cover */
             double gmin[3] = {INFINITY, INFINITY, INFINITY}, gmax[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (const HitBox& b : obox)
@@ -1793,9 +1842,25 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
         }
     }
 
+    /* the same boxes for k_shadow_group (a few hundred objects at most: the test runs once per (record, light) pair) */
+    std::vector<float4> gobox;
+    if (obox_ok && n_obj > 0 && n_obj <= 256 && !getenv("RT_NO_GROUP_CULL")) {
+        for (int o = 0; o < n_obj; o++) {
+            const HitBox& b = obox[(size_t)o];
+            const int kind = o < d->n_squares ? 0 : o < d->n_squares + d->n_spheres ? 1 : 2;
+            float kf;
+            memcpy(&kf, &kind, 4);
+            if (b.unbounded) { gobox.push_back(make_float4(-INFINITY, -INFINITY, -INFINITY, INFINITY)); gobox.push_back(make_float4(INFINITY, INFINITY, kf, 0.f)); }
+            else if (!(b.mn[0] <= b.mx[0])) { gobox.push_back(make_float4(INFINITY, INFINITY, INFINITY, -INFINITY)); gobox.push_back(make_float4(-INFINITY, -INFINITY, kf, 0.f)); }   /* cannot be hit */
+            else { gobox.push_back(make_float4(b.mn[0], b.mn[1], b.mn[2], b.mx[0])); gobox.push_back(make_float4(b.mx[1], b.mx[2], kf, 0.f)); }
+        }
+        for (int k = 0; k < 3; k++) { sc.gomin[k] = (float)(emin[k] - diag); sc.gomax[k] = (float)(emax[k] + diag); }
+    }
+    sc.n_obox = (int32_t)(gobox.size() / 2);
+    if (gobox.empty()) gobox.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
     const rt_bvh_node* dn = nullptr;
     const rt_bvh_node* dtn = nullptr;
-    if ((rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
+    if ((rc = upload(c, gobox, &sc.obox)) || (rc = upload(c, tri, &sc.tri)) || (rc = upload(c, ids, &sc.tri_ids)) || (rc = upload(c, normals, &sc.normals)) ||
         (rc = upload(c, nodes, &dn)) || (rc = upload(c, meshes, &sc.meshes)) ||
         (rc = upload(c, wnodes, &sc.wnodes)) ||
         (rc = upload(c, tnodes, &dtn)) || (rc = upload(c, tleaves, &sc.tleaves)) || (rc = upload(c, titems, &sc.titems)) ||
@@ -1993,6 +2058,9 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     c->sc = sc;
     c->front_state = -1;
     if (const char* e = getenv("RT_FRONT")) c->front_state = atoi(e) ? 1 : 0;     /* test knob: 1 = always, 0 = never */
+    c->group_state = -1; c->group_seen = 0; c->group_kept = 0;
+    c->group_min_pairs = 8192;      /* (a chunk smaller than this is not worth the read-back) */
+    if (const char* e = getenv("RT_GROUP_CULL")) { c->group_state = atoi(e) ? 1 : 0; c->group_min_pairs = 1; }  /* test knob: 1 = on every chunk, 0 = never */
     c->n_lights = d->n_lights;
     c->has_scene = true;
     return RT_OK;
@@ -2215,7 +2283,7 @@ int rt_flush(rt_ctx* c) {
         rt_stats t{};
         for (rt_ctx* q : c->subs) {
             const rt_stats& s = q->stats;
-            t.rays_primary += s.rays_primary; t.rays_secondary += s.rays_secondary; t.rays_shadow += s.rays_shadow; t.rays_shadow_culled += s.rays_shadow_culled; t.nonfinite += s.nonfinite;
+            t.rays_primary += s.rays_primary; t.rays_secondary += s.rays_secondary; t.rays_shadow += s.rays_shadow; t.rays_shadow_culled += s.rays_shadow_culled; t.rays_shadow_grouped += s.rays_shadow_grouped; t.nonfinite += s.nonfinite;
             t.iterations = std::max(t.iterations, s.iterations); t.peak_states = std::max(t.peak_states, s.peak_states);
             t.ms_total = std::max(t.ms_total, s.ms_total); t.ms_closest += s.ms_closest; t.ms_shadow += s.ms_shadow;
             t.launches_closest += s.launches_closest; t.launches_shadow += s.launches_shadow;
@@ -2531,6 +2599,7 @@ int rt_trace_static(rt_ctx* c, const float* org, const float* dir, const uint32_
     w.dcode = reinterpret_cast<unsigned long long*>(take((size_t)B * 8));
     w.dtex = reinterpret_cast<uint32_t*>(take((size_t)B * 4));
     w.cnt = reinterpret_cast<uint32_t*>(take((size_t)B * RT_MAX_LIGHTS * 4));
+    w.keys = nullptr;                       /* (no group culling on the static scratch: 4096 rays at most) */
     w.ctr = reinterpret_cast<Counters*>(take(sizeof(Counters)));
     w.tilebuf = nullptr;
     w.srays = reinterpret_cast<float4*>(take((size_t)SRAYS * 2 * sizeof(float4))); w.srays_cap = SRAYS;

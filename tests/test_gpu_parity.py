@@ -237,6 +237,7 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
                         ("RT_SEPARATE_HASH", "1"),                                       # ... the shared rounds of the counter RNG in a pass of their own (k_hash_records) instead of inside k_closest
                         ("RT_SPREAD_LANES", "0"), ("RT_SPREAD_LANES", "1048576"),           # ... small batches of bounced rays one state per lane / spread thinner than by default
                         ("RT_NO_TAIL_SWAP", "1"),                                        # ... the children of every iteration copied onto the stack (no buffer swap in the tail of the frame)
+                        ("RT_GROUP_CULL", "1"), ("RT_GROUP_CULL", "0"),                    # ... the (hit, light) pairs whose 35 rays provably meet nothing dropped on every chunk / never (k_shadow_group)
                         ("RT_SEPARATE_RAYGEN", "1"),                                     # ... primaries written out by k_raygen instead of made inside k_closest
                         ("RT_WIDE_CLOSEST", "0"), ("RT_WIDE_CLOSEST", "1"),                # ... closest hits over the reference's binary tree only / over the 4-wide quantised one in every launch (default: bounced batches)
                         ("RT_NO_CULL", "1")):                                            # ... every hit shaded and every path followed, however little it carries

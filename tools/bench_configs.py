@@ -65,13 +65,14 @@ def main():
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tot = dict(rays=0, primary=0, secondary=0, shadow=0, ms_shadow=0.0, ms_closest=0.0)
+    tot = dict(rays=0, primary=0, secondary=0, shadow=0, shadow_grouped=0, ms_shadow=0.0, ms_closest=0.0)
     for _ in range(args.steps):
         st = step()
         tot["rays"] += st.rays
         tot["primary"] += st.rays_primary
         tot["secondary"] += st.rays_secondary
         tot["shadow"] += st.rays_shadow
+        tot["shadow_grouped"] += st.rays_shadow_grouped
         tot["ms_shadow"] += st.ms_shadow
         tot["ms_closest"] += st.ms_closest
     torch.cuda.synchronize()
@@ -80,7 +81,7 @@ def main():
     print(json.dumps({
         "config": args.config, "scene": name, "tree_mode": args.tree_mode, "width": W, "height": H, "spp": spp, "max_depth": depth,
         "ms_per_frame": round(el / k * 1e3, 2), "mrays_per_s": round(tot["rays"] / el / 1e6, 2),
-        "rays_per_frame": {c: tot[c] // k for c in ("primary", "secondary", "shadow")},
+        "rays_per_frame": {c: tot[c] // k for c in ("primary", "secondary", "shadow", "shadow_grouped")},
         "kernel_ms_per_frame": {"k_shadow": round(tot["ms_shadow"] / k, 2), "k_closest": round(tot["ms_closest"] / k, 2)},
         "frame_checksum": float(frame.double().sum().item()),
     }), flush=True)
