@@ -1845,14 +1845,41 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     /* the same boxes for k_shadow_group (a few hundred objects at most: the test runs once per (record, light) pair) */
     std::vector<float4> gobox;
     if (obox_ok && n_obj > 0 && n_obj <= 256 && !getenv("RT_NO_GROUP_CULL")) {
-        for (int o = 0; o < n_obj; o++) {
-            const HitBox& b = obox[(size_t)o];
-            const int kind = o < d->n_squares ? 0 : o < d->n_squares + d->n_spheres ? 1 : 2;
+        auto put = [&](const HitBox& b, int kind) {
             float kf;
             memcpy(&kf, &kind, 4);
             if (b.unbounded) { gobox.push_back(make_float4(-INFINITY, -INFINITY, -INFINITY, INFINITY)); gobox.push_back(make_float4(INFINITY, INFINITY, kf, 0.f)); }
             else if (!(b.mn[0] <= b.mx[0])) { gobox.push_back(make_float4(INFINITY, INFINITY, INFINITY, -INFINITY)); gobox.push_back(make_float4(-INFINITY, -INFINITY, kf, 0.f)); }   /* cannot be hit */
             else { gobox.push_back(make_float4(b.mn[0], b.mn[1], b.mn[2], b.mx[0])); gobox.push_back(make_float4(b.mx[1], b.mx[2], kf, 0.f)); }
+        };
+        /* squares and spheres one box each, in ordinal order (the kernel finds their records by it); a mesh as the hit boxes of up to
+         * `per_mesh` nodes of its tree -- the box of a whole gorilla is mostly air: the node with the largest box is replaced by its
+         * two children until the budget is spent (every accepted hit lies in the hit box of its leaf, hence in one of these) */
+        for (int o = 0; o < d->n_squares + d->n_spheres; o++) put(obox[(size_t)o], o < d->n_squares ? 0 : 1);
+        int per_mesh = d->n_meshes > 0 ? std::max(1, std::min(8, (256 - d->n_squares - d->n_spheres) / d->n_meshes)) : 1;      /* (1 / 8 / 32 / 64 boxes: gorilla frame 34.8 / 32.0 / 32.5 / 33.6 ms, cow 20.1 / 20.0 / 20.8 / 22.1) */
+        if (const char* e = getenv("RT_GROUP_MESH_BOXES")) per_mesh = std::max(1, std::min(64, atoi(e)));
+        for (int mi = 0; mi < d->n_meshes; mi++) {
+            struct Part { HitBox box; int32_t link; };
+            std::vector<Part> parts{{mesh_hit[(size_t)mi], meshes[(size_t)mi].root}};
+            while ((int)parts.size() < per_mesh) {
+                int pick = -1;
+                double best = -1.0;
+                for (int i = 0; i < (int)parts.size(); i++) {
+                    const Part& pt = parts[(size_t)i];
+                    if (pt.link < 0 || pt.box.unbounded || !(pt.box.mn[0] <= pt.box.mx[0])) continue;
+                    const double a = LeafSplitter::half_area(pt.box);
+                    if (a > best) { best = a; pick = i; }
+                }
+                if (pick < 0) break;
+                const int32_t link = parts[(size_t)pick].link;
+                const rt_bvh_node& n = nodes[(size_t)link];
+                const Part l{hbox[2 * (size_t)link], n.left}, r{hbox[2 * (size_t)link + 1], n.right};
+                parts[(size_t)pick] = l;
+                parts.push_back(r);
+            }
+            for (const Part& pt : parts)
+                if (pt.box.unbounded || pt.box.mn[0] <= pt.box.mx[0]) put(pt.box, 2);      /* (a part that cannot be hit needs no box) */
+            if (parts.empty()) put(mesh_hit[(size_t)mi], 2);
         }
         for (int k = 0; k < 3; k++) { sc.gomin[k] = (float)(emin[k] - diag); sc.gomax[k] = (float)(emax[k] + diag); }
     }
