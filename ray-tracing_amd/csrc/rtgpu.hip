@@ -391,6 +391,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         uint32_t spread = 0;
         if (n_new == 0 && cblock == 64u) while (spread < 6 && ((unsigned long long)nb << (spread + 1)) <= c->spread_lanes) spread++;
         scl.spread_shift = (int32_t)spread;
+        if (wide) scl.cstack_cap = c->cstack_wide;         /* (what the kernel's stacks take in this launch: the words of its block-wide append sit behind them) */
 
         if (wide && cblock > 64u && lds_bytes_closest(c, cblock, true) + 64 > c->lds_max) cblock = 64u;
         auto launch_closest = [&](auto kern) {
