@@ -246,6 +246,12 @@ double rt_hit_excursion(const float v0[3], const float v1[3], const float v2[3],
  * goes on to the reference's test, 0 = rejected). Host only; for the tests that hold it against what the oracle accepts. */
 int rt_filter_passes(const float v0[3], const float v1[3], const float v2[3], float amax, const float origin[3], const float direction[3]);
 
+/* No counterpart in the reference: the group test that settles the shadow queries of a (hit point, light) pair without rays (k_shadow_group;
+ * rt_stats::rays_shadow_grouped), for n pairs of the caller: out[i] = 1 if Scene::isInShadow (Scene.h:160-168) is proven false for EVERY ray from
+ * pts[i] to a point within radii[i] of centres[i], 0 if not proven (or the scene has no object boxes). Diagnostic: the tests hold a 1 against
+ * rt_occluded on sampled rays. Host arrays in and out. */
+int rt_group_clear(rt_ctx*, const float* pts, const float* centres, const float* radii, int64_t n, int32_t* out);
+
 /* Fine-grained seams, host arrays in and out:
  * Scene::computeIntersection (Scene.h:84-88) on n rays (origin, direction as given to Ray()). */
 int rt_intersect(rt_ctx*, const float* org, const float* dir, int64_t n, rt_hit* out);

@@ -118,7 +118,7 @@ HIT_DTYPE = np.dtype([("exists", "<i4"), ("obj", "<i4"), ("tri", "<i4"), ("t", "
 # every symbol include/rtgpu.h and include/rthost.h declare
 EXPORTS = ["rt_init", "rt_tile_owner", "rt_shutdown", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_begin_frame", "rt_begin_frame_samples", "rt_export_accumulators", "rt_import_accumulators", "rt_continue_frame",
            "rt_render_tile", "rt_render_tiles", "rt_flush", "rt_download_framebuffer", "rt_resolve_device", "rt_resolve_rgba8_device", "rt_get_stats",
-           "rt_intersect", "rt_occluded", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion", "rt_filter_passes",
+           "rt_intersect", "rt_occluded", "rt_group_clear", "rt_trace", "rt_trace_static", "rt_camera_rays", "rt_rng", "rt_uses_quantised_shadow_nodes", "rt_hit_excursion", "rt_filter_passes",
            "rth_scene_new", "rth_scene_free", "rth_set_asset_dir", "rth_set_image_dir", "rth_add_texture", "rth_scene_setup", "rth_add_light",
            "rth_add_square", "rth_add_sphere", "rth_add_mesh", "rth_build", "rth_build_mode", "rth_scene_desc",
            "rth_ray_trace_from_camera", "rth_write_ppm", "rth_load_off", "rth_scene_save", "rth_scene_load"]
@@ -167,6 +167,7 @@ def lib():
     L.rt_filter_passes.restype = C.c_int
     L.rt_intersect.argtypes = [vp, vp, vp, i64, vp]
     L.rt_occluded.argtypes = [vp, vp, vp, i64, vp]
+    L.rt_group_clear.argtypes = [vp, vp, vp, vp, i64, vp]
     L.rt_trace.argtypes = [vp, vp, vp, vp, vp, i64, C.POINTER(RenderParams), vp]
     L.rt_trace_static.argtypes = [vp, vp, vp, vp, vp, i64, C.POINTER(RenderParams), vp]
     L.rt_camera_rays.argtypes = [vp, C.POINTER(RenderParams), i32, i32, i32, i32, vp, vp]
@@ -470,6 +471,15 @@ class Context:
         lights = np.ascontiguousarray(lights, np.float32)
         out = np.zeros(len(pts), np.int32)
         self._check(self.L.rt_occluded(self.h, _ptr(pts), _ptr(lights), len(pts), _ptr(out)), "rt_occluded")
+        return out
+
+    def group_clear(self, pts, centres, radii):
+        """1 where every shadow ray from pts[i] to the sphere (centres[i], radii[i]) is proven unoccluded by the group test (rt_group_clear)."""
+        pts = np.ascontiguousarray(pts, np.float32)
+        centres = np.ascontiguousarray(centres, np.float32)
+        radii = np.ascontiguousarray(radii, np.float32)
+        out = np.zeros(len(pts), np.int32)
+        self._check(self.L.rt_group_clear(self.h, _ptr(pts), _ptr(centres), _ptr(radii), len(pts), _ptr(out)), "rt_group_clear")
         return out
 
     def trace(self, org, dirs, params, pixel=None, sample=None, static=False):

@@ -1622,6 +1622,51 @@ RT_DEV bool hull_clear_of_box(F3 A, F3 D, float h0, float dh, float smin, float 
     }
     return empty || lo > hi;
 }
+/* the decision for one pair: hit point P, light centre C, radius R (0 for hard shadows). why: -1 clear, 0 kept for its origin or length,
+ * 1 + kind of the object that keeps it */
+RT_DEV bool group_pair_clear(const DScene& sc, const F3 P, const F3 C, const float R, int& why_out) {
+    const F3 D = sub(C, P);
+    const float dist = len(D);
+    const float big = fmaxf(fmaxf(fabsf(P.x), fabsf(P.y)), fmaxf(fabsf(P.z), fmaxf(fmaxf(fabsf(C.x), fabsf(C.y)), fabsf(C.z)))) + R;
+    const float slack = 64.f * 5.9604645e-8f * (big + dist);              /* the float arithmetic of the sample position, the origin and the hit point */
+    const float h0 = 0.002f + slack, h1 = R * 1.00001f + 0.002f + slack, dh = h1 - h0;
+    /* origins the object boxes' paddings were derived for (the light may lie outside: what the paddings bound is the rounding of a hit
+     * point, which grows with its distance from the origin, and a hit lies in an object's box, within the scene), a ray with a length */
+    bool clear = P.x >= sc.gomin[0] && P.x <= sc.gomax[0] && P.y >= sc.gomin[1] && P.y <= sc.gomax[1] && P.z >= sc.gomin[2] && P.z <= sc.gomax[2] &&
+                 dist > 4.f * h1 && dist < 1e15f && big < 1e15f;
+    /* how far back the rays' lines can matter (spheres): the admitted box's diagonal, in units of |C - P| */
+    const float back = clear ? (fabsf(sc.gomax[0] - sc.gomin[0]) + fabsf(sc.gomax[1] - sc.gomin[1]) + fabsf(sc.gomax[2] - sc.gomin[2])) / dist : 0.f;
+    int why = clear ? -1 : 0;
+    for (int o = 0; o < sc.n_obox && clear; o++) {
+        float4 b0 = sc.obox[2 * o], b1 = sc.obox[2 * o + 1];
+        const int kind = __float_as_int(b1.z);
+        if (kind == 1) {
+            /* a sphere's uploaded box is padded for the farthest admitted origin (the rounding of a root grows with the square of the
+             * origin's distance: | |hit - centre|^2 - r^2 | <= 96 u (|o - centre| + r)^2, rtgpu.hip) -- a scene with a large floor makes
+             * that metres. This pair's origins are within 0.002 of P: the same bound with their distance */
+            const float4 sp = sc.spheres[2 * (o - sc.n_squares)];
+            const float r = sp.w, oc = len(sub(P, f3(sp.x, sp.y, sp.z))) + 0.002f;
+            const float pad = 96.f * 5.9604645e-8f * (oc + r) * (oc + r) / r + 1e-5f * r + slack + 1e-6f;
+            if (r > 0.f && pad < 1e15f && b0.x <= b0.w) {
+                b0 = make_float4(sp.x - r - pad, sp.y - r - pad, sp.z - r - pad, sp.x + r + pad);
+                b1 = make_float4(sp.y + r + pad, sp.z + r + pad, b1.z, 0.f);
+            }
+        }
+        bool out = hull_clear_of_box(P, D, h0, dh, 0.f, 1.f, 1.f, b0, b1);
+        if (kind == 1) out = out && hull_clear_of_box(P, D, h0, dh, -back, 0.f, -1.f, b0, b1);
+        if (kind == 0 && !out) {
+            /* every ray has dot(d, n) > 0: (lp - P).n >= (C - P).n - R |n|, with a margin far above the rounding of the dot */
+            const float4 q3 = sc.squares[4 * o + 3];
+            const F3 n = f3(q3.x, q3.y, q3.z);
+            const float nl = len(n);
+            out = dot(D, n) > (R * 1.001f + 1e-4f * (dist + R)) * nl && nl > 0.f;
+        }
+        clear = out;
+        if (!out) why = 1 + kind;
+    }
+    why_out = clear ? -1 : why;
+    return clear;
+}
 __global__ void __launch_bounds__(256) k_shadow_group(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec, uint32_t n_rec,
                                                       uint32_t* __restrict__ keys, Counters* ctr) {
     __shared__ uint32_t s_tot[6];
@@ -1633,52 +1678,8 @@ __global__ void __launch_bounds__(256) k_shadow_group(DScene sc, FrameD fr, cons
         uint32_t rec = key, li = 0u;
         if (sc.n_lights != 1) { rec = key / (uint32_t)sc.n_lights; li = key - rec * (uint32_t)sc.n_lights; }
         const float4 q0 = reinterpret_cast<const float4*>(drec + rec)[0];
-        const F3 P = f3(q0.x, q0.y, q0.z);
         const DLight L = sc.lights[li];
-        const F3 C = f3(L.pos[0], L.pos[1], L.pos[2]);
-        const float R = fr.shadow_mode == 0 ? fabsf(L.radius) : 0.f;
-        const F3 D = sub(C, P);
-        const float dist = len(D);
-        const float big = fmaxf(fmaxf(fabsf(P.x), fabsf(P.y)), fmaxf(fabsf(P.z), fmaxf(fmaxf(fabsf(C.x), fabsf(C.y)), fabsf(C.z)))) + R;
-        const float slack = 64.f * 5.9604645e-8f * (big + dist);              /* the float arithmetic of the sample position, the origin and the hit point */
-        const float h0 = 0.002f + slack, h1 = R * 1.00001f + 0.002f + slack, dh = h1 - h0;
-        /* origins the object boxes' paddings were derived for (the light may lie outside: what the paddings bound is the rounding of a hit
-         * point, which grows with its distance from the origin, and a hit lies in an object's box, within the scene), a ray with a length */
-        bool clear = P.x >= sc.gomin[0] && P.x <= sc.gomax[0] && P.y >= sc.gomin[1] && P.y <= sc.gomax[1] && P.z >= sc.gomin[2] && P.z <= sc.gomax[2] &&
-                     dist > 4.f * h1 && dist < 1e15f && big < 1e15f;
-        /* how far back the rays' lines can matter (spheres): the admitted box's diagonal, in units of |C - P| */
-        const float back = clear ? (fabsf(sc.gomax[0] - sc.gomin[0]) + fabsf(sc.gomax[1] - sc.gomin[1]) + fabsf(sc.gomax[2] - sc.gomin[2])) / dist : 0.f;
-        int why = clear ? -1 : 0;
-        for (int o = 0; o < sc.n_obox && clear; o++) {
-            float4 b0 = sc.obox[2 * o], b1 = sc.obox[2 * o + 1];
-            const int kind = __float_as_int(b1.z);
-            if (kind == 1) {
-                /* a sphere's uploaded box is padded for the farthest admitted origin (the rounding of a root grows with the square of the
-                 * origin's distance: | |hit - centre|^2 - r^2 | <= 96 u (|o - centre| + r)^2, rtgpu.hip) -- a scene with a large floor makes
-                 * that metres. This pair's origins are within 0.002 of P: the same bound with their distance */
-                const float4 sp = sc.spheres[2 * (o - sc.n_squares)];
-                const float r = sp.w, oc = len(sub(P, f3(sp.x, sp.y, sp.z))) + 0.002f;
-                const float pad = 96.f * 5.9604645e-8f * (oc + r) * (oc + r) / r + 1e-5f * r + slack + 1e-6f;
-                if (r > 0.f && pad < 1e15f && b0.x <= b0.w) {
-                    b0 = make_float4(sp.x - r - pad, sp.y - r - pad, sp.z - r - pad, sp.x + r + pad);
-                    b1 = make_float4(sp.y + r + pad, sp.z + r + pad, b1.z, 0.f);
-                }
-            }
-            bool out = hull_clear_of_box(P, D, h0, dh, 0.f, 1.f, 1.f, b0, b1);
-            if (kind == 1) out = out && hull_clear_of_box(P, D, h0, dh, -back, 0.f, -1.f, b0, b1);
-            if (kind == 0 && !out) {
-                /* every ray has dot(d, n) > 0: (lp - P).n >= (C - P).n - R |n|, with a margin far above the rounding of the dot */
-                const float4 q3 = sc.squares[4 * o + 3];
-                const F3 n = f3(q3.x, q3.y, q3.z);
-                const float nl = len(n);
-                out = dot(D, n) > (R * 1.001f + 1e-4f * (dist + R)) * nl && nl > 0.f;
-            }
-            clear = out;
-            if (!out) why = 1 + kind;
-        }
-        keep = !clear;
-        if (!keep) why = -1;
-        why_out = why;
+        keep = !group_pair_clear(sc, f3(q0.x, q0.y, q0.z), f3(L.pos[0], L.pos[1], L.pos[2]), fr.shadow_mode == 0 ? fabsf(L.radius) : 0.f, why_out);
     }
     if (sc.group_debug) {                         /* one atomic per wave and reason */
         for (int k = 0; k < 4; k++) {
@@ -1699,6 +1700,16 @@ __global__ void __launch_bounds__(256) k_shadow_group(DScene sc, FrameD fr, cons
     }
     __syncthreads();
     if (keep) keys[s_tot[4] + s_tot[wave] + (uint32_t)__popcll(km & lt)] = key;
+}
+
+/* rt_group_clear: the same decision for pairs given by the caller (diagnostic; tests hold "clear" against Scene::isInShadow on sampled rays) */
+__global__ void __launch_bounds__(256) k_group_probe(DScene sc, const float* __restrict__ pts, const float* __restrict__ ctr, const float* __restrict__ rad,
+                                                     uint32_t n, int32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int why;
+    const bool clear = sc.n_obox > 0 && group_pair_clear(sc, f3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), f3(ctr[3 * i], ctr[3 * i + 1], ctr[3 * i + 2]), fabsf(rad[i]), why);
+    out[i] = clear ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,

@@ -2525,6 +2525,27 @@ int rt_occluded(rt_ctx* c, const float* pts, const float* lp, int64_t n, int32_t
     return RT_OK;
 }
 
+int rt_group_clear(rt_ctx* c, const float* pts, const float* centres, const float* radii, int64_t n, int32_t* out) {
+    if (c && !c->subs.empty()) { int rc = rt_group_clear(c->subs[0], pts, centres, radii, n, out); if (rc) c->err = c->subs[0]->err; return rc; }
+    if (!c || !pts || !centres || !radii || !out || n < 0 || n > 0x7FFFFFFFll) return RT_ERR_ARG;
+    if (!c->has_scene) return fail(c, RT_ERR_STATE, "no scene");
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf a, b, r, o;
+    int rc;
+    if ((rc = stage_in(c, a, pts, (size_t)n * 12)) || (rc = stage_in(c, b, centres, (size_t)n * 12)) || (rc = stage_in(c, r, radii, (size_t)n * 4)) || (rc = ensure(c, o, (size_t)n * 4))) {
+        release(a); release(b); release(r); release(o);
+        return rc;
+    }
+    hipLaunchKernelGGL(k_group_probe, dim3(((uint32_t)n + 255) / 256), dim3(256), 0, c->stream, c->sc,
+                       static_cast<const float*>(a.p), static_cast<const float*>(b.p), static_cast<const float*>(r.p), (uint32_t)n, static_cast<int32_t*>(o.p));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, o.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+    release(a); release(b); release(r); release(o);
+    if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, "rt_group_clear: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_trace(rt_ctx* c, const float* org, const float* dir, const uint32_t* pixel, const uint32_t* sample, int64_t n,
              const rt_render_params* p, float* rgb) {
     if (c && !c->subs.empty()) { int rc = rt_trace(c->subs[0], org, dir, pixel, sample, n, p, rgb); if (rc) c->err = c->subs[0]->err; return rc; }

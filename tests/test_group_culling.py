@@ -118,3 +118,53 @@ def test_random_scenes_forced_on_and_off(rt, monkeypatch, seed):
         assert onst.rays_shadow == offst.rays_shadow
         assert onst.rays_shadow_grouped > 0, (seed, shadow_mode)          # (the far parts of the floor see the small lights with nothing near)
         print(f"seed {seed} mode {shadow_mode}: {onst.rays_shadow_grouped} of {onst.rays_shadow} settled by the group test")
+
+
+@pytest.mark.parametrize("name", ["mesh_gorilla", "refraction", "reflexion_chamber", "final", "cornell_box", "stage_blob"])
+def test_a_clear_pair_has_no_occluded_ray(rt, name):
+    """The predicate itself (rt_group_clear), on pairs no frame would produce: hit points all over the scene's surfaces, lights of
+    random size anywhere around them. Wherever it says 'clear', Scene::isInShadow (rt_occluded, the exact query) must be false for
+    every ray from the point to the light's sphere -- sampled densely on the sphere, its silhouette as seen from the point included."""
+    import zlib
+    r = np.random.default_rng(zlib.crc32(name.encode()))
+    ctx = rt.Context(0)
+    try:
+        hs = rt.HostScene(name, 3, 12)
+        ctx.upload_scene(hs)
+        # hit points: what random rays from random places hit
+        n = 20000
+        org = r.uniform(-6, 6, (n, 3)).astype(np.float32)
+        dirs = r.normal(size=(n, 3)).astype(np.float32)
+        hits = ctx.intersect(org, dirs)
+        pts = hits["pos"][hits["exists"] != 0].astype(np.float32)
+        assert len(pts) > 200
+        d = hs.desc.contents
+        lights = np.array([[d.lights[i].pos[0], d.lights[i].pos[1], d.lights[i].pos[2], d.lights[i].radius] for i in range(d.n_lights)], np.float32).reshape(-1, 4)
+        m = len(pts)
+        centres = (pts + r.normal(size=(m, 3)) * r.uniform(0.5, 8.0, (m, 1))).astype(np.float32)
+        radii = (10.0 ** r.uniform(-2.5, 0.3, m)).astype(np.float32)
+        if len(lights):                                   # half of the pairs go to the scene's own lights
+            pick = r.integers(0, len(lights), m)
+            own = r.random(m) < 0.5
+            centres[own] = lights[pick[own], :3]
+            radii[own] = lights[pick[own], 3]
+        clear = ctx.group_clear(pts, centres, radii)
+        idx = np.flatnonzero(clear)
+        print(f"{name}: {len(idx)} of {m} pairs clear")
+        assert len(idx) >= 5, name
+        idx = idx[:400]
+        # rays to the sphere: random points on it, and the silhouette circle as seen from the point (the widest rays)
+        k = 96
+        u = r.normal(size=(len(idx), k, 3))
+        u /= np.linalg.norm(u, axis=2, keepdims=True)
+        axis = centres[idx] - pts[idx]
+        axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+        rim = u[:, : k // 2] - (u[:, : k // 2] * axis[:, None, :]).sum(axis=2, keepdims=True) * axis[:, None, :]
+        rim /= np.linalg.norm(rim, axis=2, keepdims=True)
+        u[:, : k // 2] = rim
+        lp = (centres[idx][:, None, :] + radii[idx][:, None, None] * u).astype(np.float32).reshape(-1, 3)
+        pp = np.repeat(pts[idx], k, axis=0)
+        occ = ctx.occluded(pp, lp)
+        assert not occ.any(), f"{name}: {int(occ.sum())} occluded rays in pairs the group test called clear"
+    finally:
+        ctx.close()
