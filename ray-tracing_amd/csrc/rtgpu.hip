@@ -721,7 +721,7 @@ struct HitBox {
  * the leaf's own box). The walks that need the reference's order inside a leaf (closest hit: the first of equal
  * t wins, Mesh.cpp:114) get each record's original position along. */
 #ifndef RT_LEAF_SPLIT
-#define RT_LEAF_SPLIT 6          /* leaves with more triangles than this get a sub-tree */
+#define RT_LEAF_SPLIT 3          /* leaves with more triangles than this get a sub-tree (6 / 3 / 2: gorilla frame 32.0 / 31.6 / 31.8 ms, cow 20.0 / 19.8 / 20.0, chamber 100.2 / 98.8 / 98.9, default scene 56.4 / 55.8 / 55.7) */
 #endif
 #ifndef RT_SPLIT_SHARE
 #define RT_SPLIT_SHARE 0.02

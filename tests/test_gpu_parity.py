@@ -228,7 +228,7 @@ def test_shadow_walk_variants_same_frame(rt, ctx, monkeypatch, name):
         c4.close()
     monkeypatch.delenv("RT_WIDE_LDS_CAP")
     assert np.array_equal(bits(spilled), bits(quant)) and sst.rays_shadow == qst.rays_shadow
-    # fat leaves walked triangle by triangle (no sub-trees), and sub-trees in every leaf of more than 6 triangles
+    # fat leaves walked triangle by triangle (no sub-trees), and sub-trees in every leaf of more than 3 triangles
     # ... and top-level rounds of k_shadow that never wait / wait for 48 lanes, top-level tables read from global memory
     for knob, value in (("RT_NO_LEAF_SPLIT", "1"), ("RT_FORCE_LEAF_SPLIT", "1"), ("RT_TOP_MIN", "1"), ("RT_TOP_MIN", "48"),
                         ("RT_TOP_GLOBAL", "1"), ("RT_FRONT", "1"), ("RT_FRONT", "0"),       # ... with and without the front pass
