@@ -346,6 +346,13 @@ def main():
                             "frac": round(hbm_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4)},
                     "executed_bytes": {"bytes_per_ray": round(ex_bpr, 1), "achieved": round(ex_bpr * rays_per_launch / avg_s / 1e9, 1),
                                        "peak": L2_PEAK_GBS, "unit": "GB/s (L2)", "frac": round(ex_bpr * rays_per_launch / avg_s / 1e9 / L2_PEAK_GBS, 4)},
+                    # what north_star asks the counters to show beside the fractions: pipe utilisation, occupancy, cache hit rates
+                    "valu_busy": round(pmc["waves_per_simd"] * pmc["SQ_ACTIVE_INST_VALU_per_launch"] / pmc["SQ_WAVE_CYCLES_per_launch"], 4),
+                    "waves_per_simd": pmc["waves_per_simd"],
+                    "wave_cycles_waiting": round(pmc["SQ_WAIT_ANY_per_launch"] / pmc["SQ_WAVE_CYCLES_per_launch"], 4),
+                    "l2_hit": round(pmc["TCC_HIT_sum_per_launch"] / (pmc["TCC_HIT_sum_per_launch"] + pmc["TCC_MISS_sum_per_launch"]), 4),
+                    "l1_hit": round(1.0 - pmc["TCP_TCC_READ_REQ_sum_per_launch"] / pmc["TCP_TOTAL_CACHE_ACCESSES_sum_per_launch"], 4),
+                    "lanes_active_node_phase": round(pmc["node_phase_lanes_active"], 4), "lanes_active_triangle_phase": round(pmc["tri_phase_lanes_active"], 4),
                     "pmc_source": pmc.get("source")})
             if per_ray:
                 bpr = algorithmic_bytes_per_ray(per_ray["shadow_nodes"], per_ray["shadow_tris"])
