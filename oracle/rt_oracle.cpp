@@ -1335,6 +1335,19 @@ int orc_scene_setup(orc_scene* sc, const char* name) {
     if (n == "stage_gorilla") return setup_stage_scene(*sc, "gorilla18_fixed.obj.off", false, 0.0125f, 0.f, V3(0.f, -1.05f, 0.f));
     if (n == "reflexion_chamber") return setup_reflexion_chamber(*sc);
     if (n == "cornell_box") return setup_cornell_box(*sc);
+    if (n == "cornell_box_black_ceiling") {
+        /* test device (tests/test_reference_image.py): the same room with a ceiling that returns no light. A pixel with the same bits in both
+         * frames shows nothing of the ceiling's shading -- the one surface of the reference's rendu.ppm this checkout cannot reproduce */
+        const int rc = setup_cornell_box(*sc);
+        if (rc == 0) { Mat& m = sc->squares[4].mat; m.tex = -1; m.nmap = -1; m.kd = V3(0.f); m.ks = V3(0.f); m.ka = V3(0.f); }
+        return rc;
+    }
+    if (n == "cornell_box_ior_1p3" || n == "cornell_box_reflectivity_0p6") {
+        /* controls of the same test: a glass of another index, a mirror of another reflectivity -- the agreement with rendu.ppm must go */
+        const int rc = setup_cornell_box(*sc);
+        if (rc == 0) { if (n == "cornell_box_ior_1p3") sc->spheres[0].mat.ior = 1.3f; else sc->spheres[1].mat.reflectivity = 0.6f; }
+        return rc;
+    }
     if (n.rfind("soup:", 0) == 0) return setup_soup(*sc, atoll(n.c_str() + 5));
     return -1;
 }
