@@ -2,8 +2,17 @@
  * rt_oracle.cpp -- CPU restatement of the per-pixel render loop of
  * Crhonopost/Ray-tracing (reference @ 2025-01-17).
  *
- * TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  PARITY UNPINNED: the reference
- * path cannot be compiled in this image (needs <GL/glut.h>) and ships no tests.
+ * TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  The reference path cannot be
+ * compiled in this image (needs <GL/glut.h>) and ships no tests, so BIT-LEVEL
+ * PARITY IS UNPINNED.  What this restatement is pinned by: the GL-free slice of
+ * the reference compiled unmodified (oracle/_ref: Vec3.h, Line.h, Trackball.cpp,
+ * stb_image.h; tests/test_oracle_pins.py), and four output frames the
+ * reference's authors committed, held statistically (no bias, median 0-2 of
+ * 255 levels): rendu.ppm -- walls, textures, normal maps, Phong, soft shadows,
+ * and its glass and mirror spheres where nothing of the ceiling shows
+ * (tests/test_reference_image.py) -- and etapes/normal_interpolation/with.ppm,
+ * without.ppm, etapes/mesh/gorilla_1.ppm for the triangle-mesh path
+ * (tests/test_stage_images.py).  DESIGN.md section 6 lists what each covers.
  *
  * Every function cites the reference file:line it restates.  Arithmetic is
  * IEEE float32 in the reference's operation order (build with
