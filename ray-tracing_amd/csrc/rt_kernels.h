@@ -1189,6 +1189,11 @@ RT_DEV bool shadow_top_item(const DScene& sc, const TopTables& tt, ShadowLane& s
  * most 32 leaves the walk is therefore a bit mask: flat_reach() runs the reference's slab test on every leaf's own box when the ray
  * is taken on -- all refilled lanes together, outside the divergent loop -- and the top-level state machine then only takes the next
  * set bit: no node steps, no stack. Mode 1 ("does an earlier leaf hold any hit at all") walks the same mask again up to its limit. */
+RT_DEV TopTables top_tables_global_flat(const DScene& sc) {      /* (only .flat is read through it) */
+    TopTables tt{};
+    tt.flat = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.top_blob) + sc.top_off[7]);
+    return tt;
+}
 RT_DEV uint32_t flat_reach(const TopTables& tt, int n_flat, const Ray& r) {
     uint32_t mask = 0u;
 #pragma unroll 1
@@ -1714,7 +1719,7 @@ __global__ void __launch_bounds__(256) k_group_probe(DScene sc, const float* __r
 
 __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, const DiffuseRec* __restrict__ drec,
                                                       const unsigned long long* __restrict__ dcode, uint32_t n_rec, int S,
-                                                      float4* __restrict__ rays) {
+                                                      float4* __restrict__ rays, uint32_t* __restrict__ masks) {
     unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long total = sc.group_keys ? (unsigned long long)sc.group_n * S : (unsigned long long)n_rec * sc.n_lights * S;
     if (idx >= total) return;
@@ -1722,6 +1727,14 @@ __global__ void __launch_bounds__(256) k_shadow_setup(DScene sc, FrameD fr, cons
     shadow_ray_of(sc, fr, drec, dcode, idx, S, key, o, d, lightDistance);
     rays[2 * idx] = make_float4(o.x, o.y, o.z, lightDistance);
     rays[2 * idx + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(key));
+    if (masks) {
+        /* the flat top-level pass of k_shadow<5> (flat_reach: the reference's slab test on every top-level leaf's own box), here with
+         * every lane busy instead of at the persistent kernel's refill, where a quarter to a half of a wave's lanes take part */
+        Ray r;
+        r.o = o; r.d = d; r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                /* AccelerationStruct.cpp:19, as at the refill */
+        TopTables tt = top_tables_global_flat(sc);
+        masks[idx] = flat_reach(tt, sc.n_flat, r);
+    }
 }
 
 /* Scenes without meshes (the refraction and reflexion scenes: a sphere and a wall): a shadow ray is a handful of object
@@ -1821,7 +1834,8 @@ __global__ void __launch_bounds__(RT_FBLOCK) k_shadow_front(DScene sc, FrameD fr
 template <int MODE, bool COUNT>        /* MODE 0: exact 64-byte nodes, 1: quantised 4-wide tree, 2: ... with sub-trees in fat leaves and batched top-level rounds, 3: ... and sub-trees over the objects of top-level leaves, 5: mode 3 with the flat top-level pass. COUNT: step and clock diagnostics (RT_COUNT=1); they cost registers, so they are compiled out otherwise */
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, 8))) k_shadow(DScene sc, const float4* __restrict__ rays, unsigned long long total, int S,
                                                         uint32_t* cnt, Counters* ctr, unsigned long long* next, int top_lds,
-                                                        int* ovf, int lds_cap, int ovf_cap, int top_min, const unsigned long long* total_ptr) {
+                                                        int* ovf, int lds_cap, int ovf_cap, int top_min, const unsigned long long* total_ptr,
+                                                        const uint32_t* __restrict__ masks) {
     constexpr bool count_steps = COUNT;
     if (total_ptr) total = *total_ptr;       /* the rays the front pass deferred (k_shadow_front) */
     constexpr bool QUANT = MODE != 0, SUB = MODE >= 2, TOPSUB = MODE == 3 || MODE == 5, FLAT = MODE == 5;
@@ -1905,7 +1919,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
                 s.r.d = f3(rd.x, rd.y, rd.z);
                 s.r.inv = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);                 /* AccelerationStruct.cpp:19 */
                 s.tri_pos = TRI_NONE;
-                if (FLAT) stk[0] = (int)flat_reach(tt, sc.n_flat, s.r);        /* (before the restart, which reads it back) */
+                if (FLAT) stk[0] = (int)masks[idx];        /* which top-level leaves the ray reaches (k_shadow_setup: flat_reach); before the restart, which reads it back */
                 shadow_restart(sc, s, 0, 0);
             }
         }

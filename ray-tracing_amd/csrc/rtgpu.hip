@@ -73,7 +73,7 @@ struct rt_ctx {
     unsigned long long queued_samples = 0;
     int32_t resolve_spp = 0;        /* sample-sharded frames (rt_begin_frame_samples): the frame's samples per pixel over ALL contexts, what a resolve divides by; 0 = this context's own count */
 
-    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, keys, ctr, tilebuf, srays, dtex, ovf;
+    DevBuf acc, nf, prim, rgb, stack, child, drec, dcode, cnt, keys, ctr, tilebuf, srays, smask, dtex, ovf;
     uint32_t batch = 32u << 20;   /* path states per wavefront iteration at most (RT_BATCH). One batch of diffuse hits is one launch of the persistent shadow kernel, and
                                    * every launch ends in a tail of a few ms in which the longest rays finish alone: measured on C5 at 1 / 4 / 8 / 16 / 32 Mi states
                                    * 1112 / 1244 / 1334 / 1340 / 1358 Mrays/s (gorilla 75.6 / 65.8 / 61.8 ms per frame with 1 / 4 / 16 Mi). What a batch really
@@ -241,6 +241,7 @@ struct WaveBufs {
     Counters* ctr;
     TileD* tilebuf;                         /* from_tiles only */
     float4* srays; unsigned long long srays_cap;    /* shadow-ray buffer, capacity in rays (2 float4 each) */
+    uint32_t* smask;                        /* per shadow ray: the top-level leaves it reaches (k_shadow<5>); nullptr = that variant is not used */
     int* ovf; size_t ovf_bytes;             /* spill slices of the 4-wide shadow walk */
     uint32_t batch;
     int persistent_blocks;
@@ -286,6 +287,8 @@ int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
     const unsigned long long chunk = std::max<unsigned long long>(1ull, std::min<unsigned long long>(B, ray_cap / per_rec));
     const bool direct = c->sc.n_meshes == 0 && !getenv("RT_NO_DIRECT_SHADOW");
     if (!direct && L > 0 && (rc = ensure(c, c->srays, (size_t)(chunk * per_rec) * 2 * sizeof(float4)))) return rc;
+    const bool want_mask = !direct && L > 0 && c->sc.n_flat > 0 && c->sc.has_topsub && c->sc.quant_ok;
+    if (want_mask && (rc = ensure(c, c->smask, (size_t)(chunk * per_rec) * sizeof(uint32_t)))) return rc;
     const int ovf_cap = wide_ovf_cap(c, nullptr);
     if ((rc = ensure(c, c->ovf, std::max<size_t>(256, (size_t)c->persistent_blocks * ovf_cap * RT_BLOCK * sizeof(int))))) return rc;
     w.stack = static_cast<PathState*>(c->stack.p); w.stack_cap = c->stack.bytes / sizeof(PathState);
@@ -295,6 +298,7 @@ int bufs_from_ctx(rt_ctx* c, const Source& src, WaveBufs& w) {
     w.keys = c->sc.n_obox > 0 ? static_cast<uint32_t*>(c->keys.p) : nullptr;
     w.tilebuf = static_cast<TileD*>(c->tilebuf.p);
     w.srays = static_cast<float4*>(c->srays.p); w.srays_cap = c->srays.bytes / (2 * sizeof(float4));
+    w.smask = want_mask ? static_cast<uint32_t*>(c->smask.p) : nullptr;
     w.ovf = static_cast<int*>(c->ovf.p); w.ovf_bytes = c->ovf.bytes;
     w.batch = B; w.persistent_blocks = c->persistent_blocks; w.timing = true;
     return RT_OK;
@@ -521,7 +525,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                     front_rays += threads;
                 } else {
                     hipLaunchKernelGGL(k_shadow_setup, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, scg, c->fr,
-                                       w.drec + r0, w.dcode + r0, nr, S, w.srays);
+                                       w.drec + r0, w.dcode + r0, nr, S, w.srays, w.smask);
                     if (w.timing) {
                         if (!(e2 = next_event(c, 1))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
                         HIP_TRY(c, hipEventRecord(e2->a, c->stream));
@@ -541,14 +545,15 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                 int top_min = c->sc.n_top_items >= 24 ? 32 : 1;       /* see k_shadow; measured on the default scene: 1, 8, 16, 32, 48, 60 -> 2365, 2205, 2065, 1828, 1839, 2111 ms */
                 if (c->sc.has_topsub) top_min = 1;                     /* (with sub-trees over the objects a top-level round is short: 32 / 16 / 8 / 1 -> 94.7 / 93.1 / 92.6 / 91.9 ms on the default scene at 4 spp) */
                 if (const char* e = getenv("RT_TOP_MIN")) top_min = std::max(1, atoi(e));
-                const bool flat_top = c->sc.quant_ok && c->sc.has_topsub && c->sc.n_flat > 0;      /* k_shadow<5>: the variant of mode 3 with the flat top-level pass (forced onto the scenes of mode 2 it loses: chamber 122 -> 137 ms, gorilla 42.3 -> 45.2, cow 29.1 -> 31.8 -- they pay for mode 3's plane filter and object sub-trees, and have two to four top-level leaves) */
+                const bool flat_top = c->sc.quant_ok && c->sc.has_topsub && c->sc.n_flat > 0 && w.smask && !front;     /* (its per-ray leaf masks come from k_shadow_setup) */      /* k_shadow<5>: the variant of mode 3 with the flat top-level pass (forced onto the scenes of mode 2 it loses: chamber 122 -> 137 ms, gorilla 42.3 -> 45.2, cow 29.1 -> 31.8 -- they pay for mode 3's plane filter and object sub-trees, and have two to four top-level leaves) */
                 DScene scs = c->sc;
                 if (!flat_top) scs.n_flat = 0;
                 auto launch = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3((uint32_t)blocks_now), dim3(RT_BLOCK), lds + (top_lds ? (size_t)c->sc.top_blob_bytes : 0), c->stream, scs,
                                        static_cast<const float4*>(w.srays), threads, S, cnt0, d_ctr, &d_ctr->work, top_lds,
                                        w.ovf, lds_cap, ovf_cap, top_min,
-                                       front ? static_cast<const unsigned long long*>(&d_ctr->deferred) : static_cast<const unsigned long long*>(nullptr));
+                                       front ? static_cast<const unsigned long long*>(&d_ctr->deferred) : static_cast<const unsigned long long*>(nullptr),
+                                       static_cast<const uint32_t*>(flat_top ? w.smask : nullptr));
                 };
                 if (flat_top) { if (c->count_steps) launch(k_shadow<5, true>); else launch(k_shadow<5, false>); }
                 else if (c->sc.quant_ok && c->sc.has_topsub) { if (c->count_steps) launch(k_shadow<3, true>); else launch(k_shadow<3, false>); }
@@ -2649,6 +2654,7 @@ int rt_trace_static(rt_ctx* c, const float* org, const float* dir, const uint32_
     w.dtex = reinterpret_cast<uint32_t*>(take((size_t)B * 4));
     w.cnt = reinterpret_cast<uint32_t*>(take((size_t)B * RT_MAX_LIGHTS * 4));
     w.keys = nullptr;                       /* (no group culling on the static scratch: 4096 rays at most) */
+    w.smask = nullptr;                      /* (... and the top-level tree walked node by node: k_shadow<3>) */
     w.ctr = reinterpret_cast<Counters*>(take(sizeof(Counters)));
     w.tilebuf = nullptr;
     w.srays = reinterpret_cast<float4*>(take((size_t)SRAYS * 2 * sizeof(float4))); w.srays_cap = SRAYS;
