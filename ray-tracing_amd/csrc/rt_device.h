@@ -8,7 +8,9 @@
  * Places where the reference promotes to double are double here as well.
  */
 #pragma once
+#ifndef RT_HOST_EMU          /* tools/emu compiles these headers with g++ behind a shim of the HIP names (a memory checker for the walks) */
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 #include <float.h>
 

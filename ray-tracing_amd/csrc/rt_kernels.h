@@ -37,7 +37,8 @@ struct DiffuseRec {         /* 64 B + code */
 };
 struct Counters {
     uint32_t n_child, n_diffuse;
-    uint32_t pad[2];
+    uint32_t walk_overflow;         /* a lane of k_shadow wanted more stack entries than wstack_cap allows (wpush): the launch's answers are void, rt_flush reports RT_ERR_LIMIT */
+    uint32_t pad;
     unsigned long long rays_primary, rays_secondary, rays_shadow, nonfinite;
     unsigned long long work;        /* next unclaimed shadow-ray index of the running k_shadow launch */
     unsigned long long deferred;    /* rays k_shadow_front handed to the running k_shadow launch */
@@ -206,7 +207,7 @@ RT_DEV void mesh_closest(const DScene& sc, const DMesh& m, const Ray& r, float b
                         if (h1) stk[lds_index(sp++, stride)] = (int)d.y;
                         if (h2) stk[lds_index(sp++, stride)] = (int)d.z;
                         if (h3) stk[lds_index(sp++, stride)] = (int)d.w;
-                    } else {
+                    } else if (sub != LINK_NONE) {       /* (a ray with a NaN in it "hits" every slot of a wide node, the unused ones with their LINK_NONE included: quant_entry drops NaN plane times) */
                         uint32_t gi = leaf_first(sub) & ~TRI_SUB;
                         for (bool last = false; !last; gi++) {
                             const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)gi;
@@ -308,7 +309,7 @@ RT_DEV void mesh_closest_wide(const DScene& sc, const DMesh& m, const Ray& r, fl
                 link = la;
                 continue;
             }
-        } else {
+        } else if (link != LINK_NONE) {          /* (LINK_NONE: the unused slot of a wide node, which only a ray with a NaN in it can "hit": quant_entry drops NaN plane times) */
             const uint32_t g = leaf_first(link);
             const float4* lq = sc.tri + RT_TRI_STRIDE * (size_t)g;
             const float4 b0 = lq[4], b1 = lq[5];
@@ -347,7 +348,7 @@ RT_DEV void mesh_closest_wide(const DScene& sc, const DMesh& m, const Ray& r, fl
                             if (h1) stk[lds_index(sp++, stride)] = (int)d.y;
                             if (h2) stk[lds_index(sp++, stride)] = (int)d.z;
                             if (h3) stk[lds_index(sp++, stride)] = (int)d.w;
-                        } else {
+                        } else if (sub != LINK_NONE) {
                             uint32_t gi = leaf_first(sub) & ~TRI_SUB;
                             for (bool last = false; !last; gi++) {
                                 const float4* q = sc.tri + RT_TRI_STRIDE * (size_t)gi;
@@ -1131,7 +1132,7 @@ RT_DEV void shadow_on_hit(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
 /* the top-level tables as k_shadow reads them: in global memory, or its LDS copy (generic pointers) */
 struct TopTables { const float4* tnodes; const uint2* tleaves; const uint32_t* titems; const float4* squares; const float4* spheres; const DMesh* meshes; const TopFrame* tf; const int* tsub; const float4* flat; };
 #define RT_TOP_LDS_MAX 2048
-struct WideStack { int* lds; int* ovf; int lds_cap; const TopFrame* tf; };
+struct WideStack { int* lds; int* ovf; int lds_cap; const TopFrame* tf; int ovf_cap; uint32_t* err; };
 RT_DEV void wpush(const WideStack& w, int& sp, int link);
 /* one object of a top-level leaf: a square or sphere is tested on the spot, a mesh is entered (st = ST_MESH on return).
  * Returns true if the caller has to return (the ray ended, restarted in mode 1, or sits in a mesh now). */
@@ -1385,13 +1386,18 @@ RT_DEV void shadow_tri_step(const DScene& sc, ShadowLane& s, uint32_t* cnt) {
 /* The 4-wide walk can have three links pending per level. Only the first lds_cap entries of a lane's stack
  * live in LDS (what keeps 16 waves on a CU); deeper ones -- rare -- go to a per-lane slice of global memory,
  * entry k of lane l of block b at ovf[(b*ovf_cap + k)*64 + l]. */
+/* The upload sizes the slice for the deepest stack the walk can build (wstack_cap, rtgpu.hip); should a walk ever want more, the entry is
+ * dropped and the launch marked (Counters::walk_overflow -> RT_ERR_LIMIT) instead of writing into the next block's slice. */
 RT_DEV void wpush(const WideStack& w, int& sp, int link) {
-    if (sp < w.lds_cap) w.lds[sp * RT_BLOCK] = link; else w.ovf[(sp - w.lds_cap) * RT_BLOCK] = link;
+    if (sp < w.lds_cap) w.lds[sp * RT_BLOCK] = link;
+    else if (sp - w.lds_cap < w.ovf_cap) w.ovf[(sp - w.lds_cap) * RT_BLOCK] = link;
+    else *w.err = 1u;
     sp++;
 }
 RT_DEV int wpop(const WideStack& w, int& sp) {
     --sp;
-    return sp < w.lds_cap ? w.lds[sp * RT_BLOCK] : w.ovf[(sp - w.lds_cap) * RT_BLOCK];
+    if (sp < w.lds_cap) return w.lds[sp * RT_BLOCK];
+    return sp - w.lds_cap < w.ovf_cap ? w.ovf[(sp - w.lds_cap) * RT_BLOCK] : LINK_NONE;
 }
 /* one 4-wide node (64 bytes: twelve packed plane pairs, four links): the nearest hit child next, the others pushed.
  * Stack traffic stays in LDS unless this step could cross lds_cap (then, and only then, the spilling push/pop run). */
@@ -1405,7 +1411,7 @@ RT_DEV void shadow_quant_step(const DScene& sc, ShadowLane& s, const WideStack& 
          * branch the compiler merges them into a select of the two addresses and a flat load, which costs a 64-bit address, both
          * memory pipes and both wait counters on every pop */
         link = w.lds[(s.msp < w.lds_cap ? s.msp : w.lds_cap - 1) * RT_BLOCK];
-        if (s.msp >= w.lds_cap) link = w.ovf[(s.msp - w.lds_cap) * RT_BLOCK];
+        if (s.msp >= w.lds_cap) link = s.msp - w.lds_cap < w.ovf_cap ? w.ovf[(s.msp - w.lds_cap) * RT_BLOCK] : LINK_NONE;     /* (a dropped entry, see wpush) */
     }
     if (TOPSUB && link == LINK_SENTINEL) {
         /* the mesh entered from the sub-tree of a top-level leaf is done: back to the scene's frame -- once the mesh's
@@ -1851,7 +1857,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     const int lane = __lane_id();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     WideStack wst;
-    wst.lds = stk; wst.lds_cap = lds_cap;
+    wst.lds = stk; wst.lds_cap = lds_cap; wst.ovf_cap = ovf_cap; wst.err = &ctr->walk_overflow;
     wst.ovf = ovf + ((size_t)blockIdx.x * ovf_cap) * RT_BLOCK + threadIdx.x;
     TopTables tt;
     {

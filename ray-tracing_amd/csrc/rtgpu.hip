@@ -334,6 +334,16 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
     if (const char* e = getenv("RT_CBLOCK")) { int v = atoi(e); if ((v == 64 || v == 128 || v == 256) && lds_bytes_closest(c, v) + 64 <= c->lds_max) cblock = (uint32_t)v; }
 
     const auto t_loop0 = std::chrono::steady_clock::now();     /* (RT_DEBUG prints each iteration's time since here) */
+    /* RT_SYNC_DEBUG=1: wait for every kernel of the loop and say which one has run (finding the kernel behind a device error) */
+    const bool sync_debug = getenv("RT_SYNC_DEBUG") != nullptr;
+    auto syncpoint = [&](const char* what) -> int {
+        if (!sync_debug) return RT_OK;
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, "after %s: %s", what, hipGetErrorString(e));
+        fprintf(stderr, "[rtgpu] done: %s\n", what);
+        fflush(stderr);
+        return RT_OK;
+    };
     /* The tail of a frame -- no primaries left, the stack empty, the children of one batch fit the next -- does not go through
      * the stack: the children of one iteration are the batch of the next where they lie, k_closest writing to the child
      * buffer and to the (empty) stack buffer in turns. No copy per iteration then: a depth-50 path inside a glass mesh is fifty
@@ -412,6 +422,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
         if (fuse_raygen && n_new) { if (wide) pick_closest(std::true_type{}, std::true_type{}); else pick_closest(std::true_type{}, std::false_type{}); }
         else { if (wide) pick_closest(std::false_type{}, std::true_type{}); else pick_closest(std::false_type{}, std::false_type{}); }
         if (e1) HIP_TRY(c, hipEventRecord(e1->b, c->stream));
+        if (int src_ = syncpoint("k_closest")) return src_;
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, d_ctr, c->d_hctr, (c->front_state < 0 && front_rays) ? 1 : 0);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
@@ -521,11 +532,13 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                     hipLaunchKernelGGL(k_shadow_front, dim3((uint32_t)((threads + RT_FBLOCK - 1) / RT_FBLOCK)), dim3(RT_FBLOCK),
                                        front_lds, c->stream, scg, c->fr,
                                        w.drec + r0, w.dcode + r0, nr, S, cnt0, w.srays, &d_ctr->deferred, &d_ctr->deferred_sum);
+                    if (int src_ = syncpoint("k_shadow_front")) return src_;
                     blocks_now = (unsigned long long)w.persistent_blocks;      /* (how many rays come through is on the device) */
                     front_rays += threads;
                 } else {
                     hipLaunchKernelGGL(k_shadow_setup, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, scg, c->fr,
                                        w.drec + r0, w.dcode + r0, nr, S, w.srays, w.smask);
+                    if (int src_ = syncpoint("k_shadow_setup")) return src_;
                     if (w.timing) {
                         if (!(e2 = next_event(c, 1))) return fail(c, RT_ERR_DEVICE, "hipEventCreate failed");
                         HIP_TRY(c, hipEventRecord(e2->a, c->stream));
@@ -561,12 +574,14 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                 else if (c->sc.quant_ok) { if (c->count_steps) launch(k_shadow<1, true>); else launch(k_shadow<1, false>); }
                 else { if (c->count_steps) launch(k_shadow<0, true>); else launch(k_shadow<0, false>); }
                 if (e2) HIP_TRY(c, hipEventRecord(e2->b, c->stream));
+                if (int src_ = syncpoint("k_shadow")) return src_;
             }
         }
         if (n_diff) {
             if (L == 0) HIP_TRY(c, hipMemsetAsync(w.cnt, 0, 256, c->stream));
             hipLaunchKernelGGL(k_shade, dim3((n_diff + 255) / 256), dim3(256), 0, c->stream, c->sc, w.drec,
                                w.dtex, n_diff, S, w.cnt, acc, nonfinite, d_ctr);
+            if (int src_ = syncpoint("k_shade")) return src_;
         }
         /* 4. push the children */
         if (n_child) {
@@ -584,6 +599,7 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, w.ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    if (c->h_ctr->walk_overflow) return fail(c, RT_ERR_LIMIT, "the stack of the shadow walk overflowed (%d entries per lane): the frame is void", c->sc.wstack_cap);
     c->stats.nonfinite += c->h_ctr->nonfinite;
     if (c->debug && c->sc.n_obox > 0 && c->group_state != 0)
         fprintf(stderr, "[rtgpu] group culling kept pairs because of: origin or length %llu, a square %llu, a sphere %llu, a mesh %llu\n",
@@ -1989,7 +2005,11 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     sc.top_cap = d->top_depth + 2;
     sc.stack_cap = sc.top_cap + max_mesh_depth + 2;
     sc.cstack_cap = sc.stack_cap + (subs.empty() ? 0 : 3 * max_wide_sub_depth + 5);
-    sc.wstack_cap = sc.top_cap + 3 * (max_wide_depth + max_wide_sub_depth) + 3 + (has_topsub ? 3 * max_wide_top_depth + 2 : 0);
+    /* The deepest stack of the 4-wide shadow walk: three links pending per level of the mesh's tree, and TWO sub-trees of fat leaves on top of
+     * each other -- a lane walks on with one leaf pending, so it can be inside the sub-tree of a fat leaf A (one entry for its root, three
+     * per level) when the triangle round tests the next pending leaf B, which pushes B's sub-tree on top of what is left of A's. Until the
+     * end of round 3 this counted one sub-tree: a walk that built both wrote into the next block's slice (found by tools/soak.sh). */
+    sc.wstack_cap = sc.top_cap + 3 * (max_wide_depth + 2 * max_wide_sub_depth) + 4 + (has_topsub ? 3 * max_wide_top_depth + 2 : 0);
     sc.has_sub = subs.empty() ? 0 : 1;
     sc.has_topsub = has_topsub ? 1 : 0;
     {   /* contribution culling (k_closest): the bound needs finite, non-negative light colours */
@@ -2096,6 +2116,22 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene_desc* d) {
     if (const char* e = getenv("RT_GROUP_CULL")) { c->group_state = atoi(e) ? 1 : 0; c->group_min_pairs = 1; }  /* test knob: 1 = on every chunk, 0 = never */
     c->n_lights = d->n_lights;
     c->has_scene = true;
+    if (const char* dir = getenv("RT_DUMP_SCENE")) {
+        /* debugging aid (tools/emu): the device scene as files -- the DScene record and every buffer it points into, with the device
+         * addresses, so that the walks can be replayed on the CPU under a memory checker */
+        const std::string base(dir);
+        if (FILE* f = fopen((base + "/dscene.bin").c_str(), "wb")) { fwrite(&c->sc, sizeof(DScene), 1, f); fclose(f); }
+        if (FILE* m = fopen((base + "/manifest.txt").c_str(), "w")) {
+            for (size_t k = 0; k < c->scene_bufs.size(); k++) {
+                const DevBuf& b = c->scene_bufs[k];
+                std::vector<unsigned char> host(b.bytes);
+                if (hipMemcpy(host.data(), b.p, b.bytes, hipMemcpyDeviceToHost) != hipSuccess) continue;
+                fprintf(m, "%zu %llx %zu\n", k, (unsigned long long)(uintptr_t)b.p, b.bytes);
+                if (FILE* f = fopen((base + "/buf_" + std::to_string(k) + ".bin").c_str(), "wb")) { fwrite(host.data(), 1, b.bytes, f); fclose(f); }
+            }
+            fclose(m);
+        }
+    }
     return RT_OK;
 }
 

@@ -326,7 +326,16 @@ def test_free_form_scene_and_edge_cases(rt, ctx):
     assert np.isnan(o).any(), "the degenerate triangle should poison some normals"
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
+def _random_scene_seeds():
+    """11-13 in the suite; RT_SOAK_SEEDS=a:b adds range(a, b) for a soak run (tools/soak.sh)."""
+    extra = os.environ.get("RT_SOAK_SEEDS", "")
+    if ":" in extra:
+        a, b = extra.split(":")
+        return [11, 12, 13] + list(range(int(a), int(b)))
+    return [11, 12, 13]
+
+
+@pytest.mark.parametrize("seed", _random_scene_seeds())
 def test_random_scenes(rt, ctx, seed):
     """Random free-form scenes -- overlapping triangle clouds at several scales and tree depths (single-leaf meshes,
     fat leaves, deep trees), slivers and degenerate triangles, spheres, walls, lights inside geometry: hits, shadow
