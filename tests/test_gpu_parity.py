@@ -327,12 +327,12 @@ def test_free_form_scene_and_edge_cases(rt, ctx):
 
 
 def _random_scene_seeds():
-    """11-13 in the suite; RT_SOAK_SEEDS=a:b adds range(a, b) for a soak run (tools/soak.sh)."""
+    """11-13 and 102 in the suite; RT_SOAK_SEEDS=a:b adds range(a, b) for a soak run (tools/soak.sh)."""
     extra = os.environ.get("RT_SOAK_SEEDS", "")
     if ":" in extra:
         a, b = extra.split(":")
-        return [11, 12, 13] + list(range(int(a), int(b)))
-    return [11, 12, 13]
+        return [11, 12, 13, 102] + list(range(int(a), int(b)))
+    return [11, 12, 13, 102]      # 102: a mirror mesh with a degenerate triangle under fat leaves -- its bounced rays carry NaNs (a memory fault until round 3)
 
 
 @pytest.mark.parametrize("seed", _random_scene_seeds())
@@ -399,6 +399,37 @@ def test_random_scenes(rt, ctx, seed):
         g = ctx.trace(co, cd, rt.make_params(56, 56, spp=1, jitter=0, max_depth=6, shadow_mode=shadow_mode, seed=seed))
         o = os_.trace(co, cd, O.make_params(56, 56, spp=1, max_depth=6, shadow_mode=shadow_mode, seed=seed))
         radiance_check(g, o, f"random scene {seed} mode {shadow_mode}")
+
+
+@pytest.mark.parametrize("name", ["mesh_gorilla", "final", "soup:20000"])
+def test_rays_with_nan_and_infinite_components(rt, ctx, name):
+    """Rays no camera makes but a bounce off a degenerate triangle's normal does (Mesh.cpp:130 normalises a zero vector), and the seams
+    accept: NaN and infinite origins and directions, zero directions, origins far outside the scene. A NaN plane time is dropped by the
+    conservative box test, so such a ray "hits" every slot of a 4-wide node, the unused ones included; the walks must not follow those
+    (a memory fault until round 3). Hits, shadow answers and radiance as the oracle's, which walks the reference's tree with the same rays."""
+    hs, os_ = scene_pair(rt, ctx, name, 12 if not name.startswith("soup") else 16)
+    r = np.random.default_rng(5)
+    n = 1536
+    org = r.uniform(-3, 3, (n, 3)).astype(np.float32)
+    dirs = r.normal(size=(n, 3)).astype(np.float32)
+    k = np.arange(n) % 8
+    org[k == 0] = np.nan
+    dirs[k == 0] = np.nan
+    dirs[k == 1, 0] = np.nan
+    org[k == 2, 1] = np.inf
+    org[k == 3] = np.array([1e30, -1e30, 1e28], np.float32)
+    dirs[k == 4] = 0.0
+    org[k == 5, 2] = np.nan
+    dirs[k == 6, 1] = -np.inf
+    assert_hits_equal(ctx.intersect(org, dirs), os_.intersect(org, dirs), f"{name}: odd rays")
+    lights = r.uniform(-4, 6, (n, 3)).astype(np.float32)
+    pts = org.copy()
+    assert np.array_equal(ctx.occluded(pts, lights), os_.shadow(pts, lights))
+    g = ctx.trace(org, dirs, rt.make_params(n, 1, spp=1, jitter=0, max_depth=4, shadow_mode=0, seed=3))
+    o = os_.trace(org, dirs, O.make_params(n, 1, spp=1, max_depth=4, shadow_mode=0, seed=3))
+    assert np.array_equal(np.isnan(g), np.isnan(o)) and np.array_equal(np.isinf(g), np.isinf(o))
+    m = np.isfinite(o)
+    assert np.max(np.abs(g[m] - o[m]), initial=0.0) <= 1.0 / 255.0
 
 
 @pytest.mark.parametrize("mesh_depth", [3, 12])
