@@ -401,6 +401,51 @@ def test_random_scenes(rt, ctx, seed):
         radiance_check(g, o, f"random scene {seed} mode {shadow_mode}")
 
 
+def _frame_seeds():
+    extra = os.environ.get("RT_SOAK_FRAME_SEEDS", "")
+    if ":" in extra:
+        a, b = extra.split(":")
+        return [21, 102] + list(range(int(a), int(b)))
+    return [21, 102]
+
+
+@pytest.mark.parametrize("seed", _frame_seeds())
+def test_random_scene_frames(rt, ctx, monkeypatch, seed):
+    """The frame path (queued tiles, primaries made inside k_closest, jitter, several samples per pixel, the front pass, group culling forced
+    on a second context) on the random scenes of test_random_scenes: primary ids and ray counts exact, radiance <= 1/255 against the oracle;
+    RT_SOAK_FRAME_SEEDS=a:b adds seeds (tools/soak.sh)."""
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emu")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from dump_seed import build
+    hs, os_, lights, meshes, r = build(seed, rt)
+    ctx.upload_scene(hs)
+    gc, oc = rt.default_camera(1.0, zoom=0.0, z=-9.0), O.default_camera(1.0, zoom=0.0, z=-9.0)
+    for shadow_mode in (0, 1):
+        gp = rt.make_params(40, 40, spp=2, max_depth=6, jitter=1, shadow_mode=shadow_mode, seed=seed)
+        op = O.make_params(40, 40, spp=2, max_depth=6, jitter=1, shadow_mode=shadow_mode, seed=seed)
+        rgb, prim, st = ctx.render(gc, gp)
+        orgb, oprim, ost, _ = os_.render(oc, op, threads=8)
+        oprim_u = oprim.astype(np.int64)
+        oprim_u[oprim[..., 0] < 0] = 0xFFFFFFFF
+        assert np.array_equal(prim.astype(np.int64), oprim_u), f"seed {seed}: primary-hit primitive ids differ"
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (ost.rays_primary, ost.rays_secondary, ost.rays_shadow)
+        assert np.array_equal(np.isinf(rgb), np.isinf(orgb))
+        fin = np.isfinite(orgb) | np.isnan(orgb)
+        radiance_check(np.where(fin, rgb, 0.0), np.where(fin, orgb, 0.0), f"random frame {seed} mode {shadow_mode}")
+        if shadow_mode == 0:
+            monkeypatch.setenv("RT_GROUP_CULL", "1")
+            c2 = rt.Context(0)
+            try:
+                c2.upload_scene(hs)
+                rgb2, prim2, st2 = c2.render(gc, gp)
+            finally:
+                c2.close()
+            monkeypatch.delenv("RT_GROUP_CULL")
+            assert np.array_equal(bits(rgb2), bits(rgb)) and np.array_equal(prim2, prim) and st2.rays_shadow == st.rays_shadow
+
+
 @pytest.mark.parametrize("name", ["mesh_gorilla", "final", "soup:20000"])
 def test_rays_with_nan_and_infinite_components(rt, ctx, name):
     """Rays no camera makes but a bounce off a degenerate triangle's normal does (Mesh.cpp:130 normalises a zero vector), and the seams
