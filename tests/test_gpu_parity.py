@@ -446,6 +446,53 @@ def test_random_scene_frames(rt, ctx, monkeypatch, seed):
             assert np.array_equal(bits(rgb2), bits(rgb)) and np.array_equal(prim2, prim) and st2.rays_shadow == st.rays_shadow
 
 
+def _wide_seeds():
+    extra = os.environ.get("RT_SOAK_WIDE_SEEDS", "")
+    if ":" in extra:
+        a, b = extra.split(":")
+        return [31, 32] + list(range(int(a), int(b)))
+    return [31, 32]
+
+
+@pytest.mark.parametrize("seed", _wide_seeds())
+def test_random_scenes_of_the_second_family(rt, ctx, seed):
+    """tools/emu/dump_seed.py build_wide: soups of thousands of small triangles with huge ones mixed in, up to 40 spheres, one to four lights of
+    any size, every material kind, tree depths 2..22 and top-level depths 1..6 -- the kernel variants the first family rarely selects (plain
+    4-wide walk, batched top-level rounds, sub-trees over objects with the flat pass). Hits bit-exact, shadow queries exact, a small frame
+    within 1/255 with exact ray counts; RT_SOAK_WIDE_SEEDS=a:b adds seeds."""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emu")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from dump_seed import build_wide
+    hs, os_, lights, meshes, r = build_wide(seed, rt)
+    ctx.upload_scene(hs)
+    n = 3000
+    org = r.uniform(-6, 6, (n, 3)).astype(np.float32)
+    dirs = r.normal(size=(n, 3)).astype(np.float32)
+    dirs[:30, 0] = 0.0
+    dirs[30:50, 1:] = 0.0
+    assert_hits_equal(ctx.intersect(org, dirs), os_.intersect(org, dirs), f"wide scene {seed}")
+    lp = np.asarray([lights[int(i)][0] for i in r.integers(0, len(lights), n)], np.float32)
+    pts = org.copy()
+    v0 = meshes[0][0]
+    pts[: n // 2] = v0[r.integers(0, len(v0), n // 2)] + r.normal(size=(n // 2, 3)).astype(np.float32) * 0.03
+    assert np.array_equal(ctx.occluded(pts, lp), os_.shadow(pts, lp))
+    gc, oc = rt.default_camera(1.0, zoom=0.0, z=-10.0), O.default_camera(1.0, zoom=0.0, z=-10.0)
+    for shadow_mode in (0, 1):
+        gp = rt.make_params(32, 32, spp=1, max_depth=5, jitter=1, shadow_mode=shadow_mode, seed=seed)
+        op = O.make_params(32, 32, spp=1, max_depth=5, jitter=1, shadow_mode=shadow_mode, seed=seed)
+        rgb, prim, st = ctx.render(gc, gp)
+        orgb, oprim, ost, _ = os_.render(oc, op, threads=8)
+        oprim_u = oprim.astype(np.int64)
+        oprim_u[oprim[..., 0] < 0] = 0xFFFFFFFF
+        assert np.array_equal(prim.astype(np.int64), oprim_u), f"wide scene {seed}: primary-hit primitive ids differ"
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow + st.rays_shadow_culled) == (ost.rays_primary, ost.rays_secondary, ost.rays_shadow)
+        assert np.array_equal(np.isinf(rgb), np.isinf(orgb))
+        fin = np.isfinite(orgb) | np.isnan(orgb)
+        radiance_check(np.where(fin, rgb, 0.0), np.where(fin, orgb, 0.0), f"wide scene {seed} mode {shadow_mode}")
+
+
 @pytest.mark.parametrize("name", ["mesh_gorilla", "final", "soup:20000"])
 def test_rays_with_nan_and_infinite_components(rt, ctx, name):
     """Rays no camera makes but a bounce off a degenerate triangle's normal does (Mesh.cpp:130 normalises a zero vector), and the seams

@@ -59,16 +59,72 @@ def build(seed, rt):
     return hs, os_, lights, meshes, r
 
 
+def build_wide(seed, rt):
+    """A second family of random scenes for the soak runs: triangle soups of a few thousand small triangles with a few huge ones mixed in,
+    tree depths 2..22, up to 40 spheres (many-object top levels: batched top-level rounds, sub-trees over objects, the flat pass), one to four
+    lights of any size, glass / mirror / checker / diffuse materials at random."""
+    r = np.random.default_rng(seed)
+    hs, os_ = rt.HostScene(), O.Scene()
+    meshes = []
+    for k in range(int(r.integers(1, 5))):
+        nt = int(r.integers(200, 6000))
+        ext = float(10.0 ** r.uniform(-0.5, 0.7))
+        size = float(10.0 ** r.uniform(-2.0, -0.3)) * ext
+        c = r.uniform(-ext, ext, (nt, 3))
+        e1, e2 = r.uniform(-size, size, (nt, 3)), r.uniform(-size, size, (nt, 3))
+        big = r.random(nt) < 0.01
+        e1[big] *= 20.0
+        e2[big] *= 20.0
+        centre = r.uniform(-2, 2, 3)
+        v = np.stack([c, c + e1, c + e2], axis=1).reshape(-1, 3) + centre
+        t = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+        if r.random() < 0.5:                           # shared vertices: a random re-indexing of a tenth of the corners
+            m = r.random(3 * nt) < 0.1
+            t = t.reshape(-1)
+            t[m] = r.integers(0, 3 * nt, int(m.sum()))
+            t = t.reshape(nt, 3)
+        meshes.append((v.astype(np.float32), t.astype(np.uint32)))
+    spheres = [(r.uniform(-5, 5, 3).astype(np.float32), float(10.0 ** r.uniform(-1.3, 0.3))) for _ in range(int(r.integers(0, 41)))]
+    wall = np.array([[-9, -5, -8], [9, -5, -8], [9, 7, -8], [-9, 7, -8]], np.float32)
+    floor = np.array([[-9, -5, 7], [9, -5, 7], [9, -5, -8], [-9, -5, -8]], np.float32)
+    mesh_depth, top_depth = int(r.integers(2, 23)), int(r.integers(1, 7))
+    lights = [(r.uniform(-4, 6, 3).astype(np.float32).tolist(), float(10.0 ** r.uniform(-1.5, 0.8))) for _ in range(int(r.integers(1, 5)))]
+    for s, M in ((hs, rt), (os_, O)):
+        def mat(k):
+            m = M.Material()
+            g = np.random.default_rng(7919 * seed + k)
+            c = g.uniform(0.1, 1.0, 3)
+            m.kd[:] = c.tolist()
+            m.ks[:] = g.uniform(0.1, 1.0, 3).tolist()
+            m.shininess = float(g.uniform(1.0, 40.0))
+            m.type = int(g.integers(0, 4))
+            m.ior = float(g.uniform(1.05, 1.8))
+            m.transparency = float(g.uniform(0.1, 0.9)) if m.type == 1 else 0.0
+            m.reflectivity = float(g.uniform(0.2, 0.9)) if m.type == 2 else 0.0
+            return m
+        for lp, rad in lights:
+            s.add_light(lp, rad)
+        s.add_square(wall, mat(0))
+        s.add_square(floor, mat(1))
+        for k, (c, rad) in enumerate(spheres):
+            s.add_sphere(c, rad, mat(10 + k))
+        for k, (v, t) in enumerate(meshes):
+            s.add_mesh(v, t, mat(100 + k))
+        s.build(top_depth, mesh_depth)
+    return hs, os_, lights, meshes, r
+
+
 def main():
     seed, out = int(sys.argv[1]), sys.argv[2]
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"            # the second family (build_wide)
     os.makedirs(out, exist_ok=True)
     os.environ["RT_DUMP_SCENE"] = out
     rt = importlib.import_module("ray-tracing_amd")
-    hs, os_, lights, meshes, r = build(seed, rt)
+    hs, os_, lights, meshes, r = (build_wide if wide else build)(seed, rt)
     ctx = rt.Context(0)
     ctx.upload_scene(hs)
     ctx.close()
-    oc = O.default_camera(1.0, zoom=0.0, z=-9.0)
+    oc = O.default_camera(1.0, zoom=0.0, z=-10.0 if wide else -9.0)
     co, cd = O.camera_rays(oc, O.make_params(56, 56, spp=1), 0, 0, 56, 56)
     h = os_.intersect(co, cd)
     pos = h["pos"][h["exists"] != 0]
