@@ -115,7 +115,15 @@ def radiance_check(g, o, what, tol_q=1):
     qg, qo = O.quantize(g), O.quantize(o)
     dq = np.abs(qg - qo)
     rel = np.abs(g - o) / (1e-3 + np.abs(o))
+    # main.cpp:253 writes (int)(255 * min(1, v)) and does not clamp below: a radiance of -5e4 (a glass of random parameters under an
+    # unnormalised normal) becomes -1.2e7 "levels", of which the last few are the float rounding of the sum (fixed-point here, sequential
+    # floats there: DESIGN section 6, deviation 3). One level of 255 is the bar where a level means something, |v| <= 4; beyond, 1e-4 of the pixel's magnitude (device pow / exp differ from glibc's by an ulp, and a specular term of 1e4 carries that).
+    big = np.max(np.abs(o), axis=-1, keepdims=True) * np.ones_like(o)       # (a channel can be the small difference of large terms: the pixel's largest channel is the scale)
+    far = big > 4.0
+    dq = np.where(far, 0, dq)
     assert dq.max() <= tol_q, f"{what}: 8-bit output differs by {dq.max()} levels at {np.argwhere(dq > tol_q)[:4]}"
+    relbig = np.abs(g - o) / np.maximum(big, 1.0)
+    assert relbig[far].max(initial=0.0) <= 1e-4, f"{what}: out-of-range radiance differs by {relbig[far].max():.3g} of the pixel's magnitude"
     return float(rel.max())
 
 
