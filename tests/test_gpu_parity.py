@@ -429,10 +429,12 @@ def test_random_scene_frames(rt, ctx, monkeypatch, seed):
     from dump_seed import build
     hs, os_, lights, meshes, r = build(seed, rt)
     ctx.upload_scene(hs)
-    gc, oc = rt.default_camera(1.0, zoom=0.0, z=-9.0), O.default_camera(1.0, zoom=0.0, z=-9.0)
+    asp = (17 + seed % 37) / (9 + seed % 29)
+    gc, oc = rt.default_camera(asp, zoom=0.0, z=-9.0), O.default_camera(asp, zoom=0.0, z=-9.0)
     for shadow_mode in (0, 1):
-        gp = rt.make_params(40, 40, spp=2, max_depth=6, jitter=1, shadow_mode=shadow_mode, seed=seed)
-        op = O.make_params(40, 40, spp=2, max_depth=6, jitter=1, shadow_mode=shadow_mode, seed=seed)
+        w, h, spp = 17 + seed % 37, 9 + seed % 29, 1 + seed % 3                  # ragged tiles at both edges, one to three samples
+        gp = rt.make_params(w, h, spp=spp, max_depth=6, jitter=1, shadow_mode=shadow_mode, seed=seed)
+        op = O.make_params(w, h, spp=spp, max_depth=6, jitter=1, shadow_mode=shadow_mode, seed=seed)
         rgb, prim, st = ctx.render(gc, gp)
         orgb, oprim, ost, _ = os_.render(oc, op, threads=8)
         oprim_u = oprim.astype(np.int64)
