@@ -454,6 +454,27 @@ def test_random_scene_frames(rt, ctx, monkeypatch, seed):
                 c2.close()
             monkeypatch.delenv("RT_GROUP_CULL")
             assert np.array_equal(bits(rgb2), bits(rgb)) and np.array_equal(prim2, prim) and st2.rays_shadow == st.rays_shadow
+            # the same frame from a context of three sub-contexts (tiles dealt inside the library, gathered on the first)
+            c3 = rt.Context(devices=[0, 0, 0])
+            try:
+                c3.upload_scene(hs)
+                rgb3, prim3, st3 = c3.render(gc, gp)
+            finally:
+                c3.close()
+            assert np.array_equal(bits(rgb3), bits(rgb)) and np.array_equal(prim3, prim) and st3.rays == st.rays
+            # ... and its rays through rt_trace and the entry point that allocates nothing (which may refuse a scene whose walks need more
+            # spill entries than its scratch holds -- then with RT_ERR_LIMIT, not with a wrong answer)
+            ctx.set_camera(gc)
+            org, dirs = ctx.camera_rays(gp, 0, 0, w, h)
+            pixel = (np.arange(len(org), dtype=np.uint32) // spp).astype(np.uint32)
+            sample = (np.arange(len(org), dtype=np.uint32) % spp).astype(np.uint32)
+            want = ctx.trace(org, dirs, gp, pixel, sample)
+            try:
+                got = ctx.trace(org, dirs, gp, pixel, sample, static=True)
+            except rt.RtError as e:
+                assert "scratch" in str(e) or "limit" in str(e).lower() or "more than" in str(e), str(e)
+            else:
+                assert np.array_equal(bits(got), bits(want)), f"seed {seed}: rt_trace_static differs from rt_trace"
 
 
 def _wide_seeds():
