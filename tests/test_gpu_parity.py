@@ -524,6 +524,69 @@ def test_random_scenes_of_the_second_family(rt, ctx, seed):
         radiance_check(np.where(fin, rgb, 0.0), np.where(fin, orgb, 0.0), f"wide scene {seed} mode {shadow_mode}")
 
 
+def _grid_seeds():
+    extra = os.environ.get("RT_SOAK_GRID_SEEDS", "")
+    if ":" in extra:
+        a, b = extra.split(":")
+        return [41, 42, 43] + list(range(int(a), int(b)))
+    return [41, 42, 43]
+
+
+@pytest.mark.parametrize("seed", _grid_seeds())
+def test_rays_through_shared_vertices_and_edges(rt, ctx, seed):
+    """Height fields and flat grids (every inner vertex shared by six triangles, every edge by two), one to three of them stacked, and rays aimed
+    EXACTLY at vertices, edge midpoints and along grid lines: several triangles of several leaves answer with the very same t, and the
+    reference keeps the first it meets (Mesh.cpp:114, strict <; near child first, AccelerationStruct.cpp:273). Hit identities and bits
+    against the oracle for the 4-wide walk (rt_intersect) at tree depths 1..16; shadow queries from the vertices; RT_SOAK_GRID_SEEDS=a:b."""
+    r = np.random.default_rng(seed)
+    hs, os_ = rt.HostScene(), O.Scene()
+    n = int(r.integers(4, 28))
+    flat = bool(r.integers(0, 2))
+    layers = int(r.integers(1, 4))
+    step = float(2.0 ** r.integers(-4, 1))                       # a power of two: grid coordinates are exact
+    xs = (np.arange(n + 1) - n // 2) * step
+    gx, gy = np.meshgrid(xs, xs, indexing="ij")
+    meshes = []
+    for k in range(layers):
+        z = np.zeros_like(gx) if flat else np.round(r.normal(size=gx.shape) * 4) * (step / 4)
+        v = np.stack([gx, gy, z + k * (0.0 if r.random() < 0.5 else step)], axis=-1).reshape(-1, 3).astype(np.float32)
+        idx = np.arange((n + 1) * (n + 1)).reshape(n + 1, n + 1)
+        a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel()
+        t = np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)]).astype(np.uint32)
+        t = t[r.permutation(len(t))]
+        meshes.append((v, t))
+    mesh_depth = int(r.integers(1, 17))
+    for s, M in ((hs, rt), (os_, O)):
+        m = M.Material()
+        m.kd[:] = [0.7, 0.6, 0.5]
+        m.ks[:] = [0.3, 0.3, 0.3]
+        m.shininess = 8.0
+        s.add_light([0.3, 0.2, 5.0], 0.5)
+        for v, t in meshes:
+            s.add_mesh(v, t, m)
+        s.build(2, mesh_depth)
+    ctx.upload_scene(hs)
+    v = meshes[0][0]
+    tri = meshes[0][1]
+    targets = [v[r.integers(0, len(v), 1500)],                                                    # vertices
+               0.5 * (v[tri[r.integers(0, len(tri), 1500), 0]] + v[tri[r.integers(0, len(tri), 1500), 1]]),   # midpoints of vertex pairs (edges among them)
+               v[r.integers(0, len(v), 500)] + np.array([step / 2, 0, 0], np.float32)]            # points on grid lines
+    tg = np.concatenate(targets).astype(np.float32)
+    org = np.empty_like(tg)
+    k = np.arange(len(tg)) % 4
+    org[:] = np.array([0.0, 0.0, 8.0], np.float32)                                                # a pin-hole above the grid
+    org[k == 1] = tg[k == 1] + np.array([0.0, 0.0, 4.0], np.float32)                              # straight down: axis-parallel
+    org[k == 2] = tg[k == 2] + np.array([2.0, 0.0, 2.0], np.float32)                              # in a grid plane
+    org[k == 3] = tg[k == 3] + np.array([1.0, 1.0, 1.0], np.float32)                              # along a cell diagonal
+    dirs = (tg - org).astype(np.float32)
+    assert_hits_equal(ctx.intersect(org, dirs), os_.intersect(org, dirs), f"grid scene {seed} (n {n}, flat {flat}, layers {layers}, depth {mesh_depth})")
+    lp = np.tile(np.array([[0.3, 0.2, 5.0]], np.float32), (len(tg), 1))
+    assert np.array_equal(ctx.occluded(tg, lp), os_.shadow(tg, lp))
+    g = ctx.trace(org[:1024], dirs[:1024], rt.make_params(1024, 1, spp=1, jitter=0, max_depth=3, shadow_mode=1, seed=seed))
+    o = os_.trace(org[:1024], dirs[:1024], O.make_params(1024, 1, spp=1, max_depth=3, shadow_mode=1, seed=seed))
+    radiance_check(g, o, f"grid scene {seed}")
+
+
 @pytest.mark.parametrize("name", ["mesh_gorilla", "final", "soup:20000"])
 def test_rays_with_nan_and_infinite_components(rt, ctx, name):
     """Rays no camera makes but a bounce off a degenerate triangle's normal does (Mesh.cpp:130 normalises a zero vector), and the seams
