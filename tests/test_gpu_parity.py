@@ -446,6 +446,7 @@ def test_random_scene_frames(rt, ctx, monkeypatch, seed):
         radiance_check(np.where(fin, rgb, 0.0), np.where(fin, orgb, 0.0), f"random frame {seed} mode {shadow_mode}")
         if shadow_mode == 0:
             monkeypatch.setenv("RT_GROUP_CULL", "1")
+            monkeypatch.setenv("RT_BATCH", "1024")           # ... and in batches of 1024 states: several iterations, the LIFO stack in use
             c2 = rt.Context(0)
             try:
                 c2.upload_scene(hs)
@@ -453,6 +454,7 @@ def test_random_scene_frames(rt, ctx, monkeypatch, seed):
             finally:
                 c2.close()
             monkeypatch.delenv("RT_GROUP_CULL")
+            monkeypatch.delenv("RT_BATCH")
             assert np.array_equal(bits(rgb2), bits(rgb)) and np.array_equal(prim2, prim) and st2.rays_shadow == st.rays_shadow
             # the same frame from a context of three sub-contexts (tiles dealt inside the library, gathered on the first)
             c3 = rt.Context(devices=[0, 0, 0])
