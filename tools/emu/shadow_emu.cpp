@@ -88,7 +88,11 @@ int main(int argc, char** argv) {
     Emu e;
     {
         FILE* f = fopen((dir + "/dscene.bin").c_str(), "rb");
-        if (!f || fread(&e.sc, sizeof(DScene), 1, f) != 1) { fprintf(stderr, "no dscene.bin\n"); return 2; }
+        if (!f) { fprintf(stderr, "no dscene.bin\n"); return 2; }
+        fseek(f, 0, SEEK_END);
+        if ((size_t)ftell(f) != sizeof(DScene)) { fprintf(stderr, "dscene.bin was written by a library with another DScene layout (%ld bytes, this build has %zu): dump the scene again\n", ftell(f), sizeof(DScene)); return 3; }
+        fseek(f, 0, SEEK_SET);
+        if (fread(&e.sc, sizeof(DScene), 1, f) != 1) { fprintf(stderr, "dscene.bin unreadable\n"); return 2; }
         fclose(f);
         FILE* m = fopen((dir + "/manifest.txt").c_str(), "r");
         if (!m) { fprintf(stderr, "no manifest\n"); return 2; }
