@@ -214,7 +214,9 @@ int rt_render_tiles(rt_ctx*, const int32_t* xywh, int64_t n);
  * which is what the queues hold, and the path-state stack holds batch x (max_depth + 3): by construction they cannot
  * overflow. The kernels nevertheless bound every append (a state that does not fit is dropped, never written out of
  * range) and the host compares the counters with the capacities after every iteration: RT_ERR_LIMIT ("queue overflow")
- * would report a dropped state instead of returning a frame that misses it. */
+ * would report a dropped state instead of returning a frame that misses it. The same holds for the per-lane stacks of the shadow walk:
+ * their spill slices are sized at upload for the deepest stack the walk can build, a push beyond that is dropped, not written, and
+ * the call returns RT_ERR_LIMIT ("the stack of the shadow walk overflowed"). */
 int rt_flush(rt_ctx*);
 /* pixel_color /= nsamples (main.cpp:219) for the whole image, rows top to bottom, into host memory.
  * prim_id (optional): 2 x uint32 per pixel = (object ordinal, triangle index) of sample 0's primary hit,
