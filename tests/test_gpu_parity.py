@@ -521,8 +521,11 @@ def test_random_scenes_of_the_second_family(rt, ctx, seed):
         oprim_u[oprim[..., 0] < 0] = 0xFFFFFFFF
         assert np.array_equal(prim.astype(np.int64), oprim_u), f"wide scene {seed}: primary-hit primitive ids differ"
         assert (st.rays_primary, st.rays_secondary, st.rays_shadow + st.rays_shadow_culled) == (ost.rays_primary, ost.rays_secondary, ost.rays_shadow)
-        assert np.array_equal(np.isinf(rgb), np.isinf(orgb))
-        fin = np.isfinite(orgb) | np.isnan(orgb)
+        # deviation 3 of DESIGN section 6: the fixed-point accumulators report a channel that reaches 6e7 (a specular term under an unnormalised
+        # normal out of a random normal map) as infinite, the reference's float sum carries it on
+        huge = np.abs(np.nan_to_num(orgb, nan=0.0, posinf=0.0, neginf=0.0)) >= 5.0e7 / max(1, gp.spp)
+        assert np.array_equal(np.isinf(rgb) & ~huge, np.isinf(orgb) & ~huge)
+        fin = (np.isfinite(orgb) | np.isnan(orgb)) & ~huge & ~np.isinf(rgb)
         radiance_check(np.where(fin, rgb, 0.0), np.where(fin, orgb, 0.0), f"wide scene {seed} mode {shadow_mode}")
 
 

@@ -89,10 +89,22 @@ def build_wide(seed, rt):
     floor = np.array([[-9, -5, 7], [9, -5, 7], [9, -5, -8], [-9, -5, -8]], np.float32)
     mesh_depth, top_depth = int(r.integers(2, 23)), int(r.integers(1, 7))
     lights = [(r.uniform(-4, 6, 3).astype(np.float32).tolist(), float(10.0 ** r.uniform(-1.5, 0.8))) for _ in range(int(r.integers(1, 5)))]
+    tg = np.random.default_rng(seed + 12345)                   # every third seed: image textures and normal maps (Material.h:86-126) on random materials
+    textured = seed % 3 == 0
+    images = [tg.integers(0, 256, (int(tg.integers(1, 40)), int(tg.integers(1, 40)), int(tg.integers(3, 5)))).astype(np.uint8) for _ in range(3)] if textured else []
     for s, M in ((hs, rt), (os_, O)):
+        tex = [s.add_texture(im) for im in images]
+
         def mat(k):
             m = M.Material()
             g = np.random.default_rng(7919 * seed + k)
+            if textured:
+                g2 = np.random.default_rng(104729 * seed + k)
+                if g2.random() < 0.5:
+                    m.texture = tex[int(g2.integers(0, 3))]
+                if g2.random() < 0.4:
+                    m.normal_map = tex[int(g2.integers(0, 3))]
+                m.material_scale = float(g2.choice([1.0, 0.5, 3.0, 7.3]))
             c = g.uniform(0.1, 1.0, 3)
             m.kd[:] = c.tolist()
             m.ks[:] = g.uniform(0.1, 1.0, 3).tolist()
