@@ -483,8 +483,8 @@ def _wide_seeds():
     extra = os.environ.get("RT_SOAK_WIDE_SEEDS", "")
     if ":" in extra:
         a, b = extra.split(":")
-        return [31, 32] + list(range(int(a), int(b)))
-    return [31, 32]
+        return [31, 32, 33] + list(range(int(a), int(b)))
+    return [31, 32, 33]          # 33: with random textures and normal maps
 
 
 @pytest.mark.parametrize("seed", _wide_seeds())
