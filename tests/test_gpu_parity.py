@@ -592,6 +592,48 @@ def test_rays_through_shared_vertices_and_edges(rt, ctx, seed):
     radiance_check(g, o, f"grid scene {seed}")
 
 
+def _hall_seeds():
+    extra = os.environ.get("RT_SOAK_HALL_SEEDS", "")
+    if ":" in extra:
+        a, b = extra.split(":")
+        return [51, 52] + list(range(int(a), int(b)))
+    return [51, 52]
+
+
+@pytest.mark.parametrize("seed", _hall_seeds())
+def test_random_halls_of_mirrors_at_depth_50(rt, ctx, monkeypatch, seed):
+    """The second family without glass and with three mirrors in five materials, at the reference's depth limit (Scene.h:284): paths that
+    bounce fifty times between mirror spheres, walls and soups -- the LIFO stack, the tail of small batches, the spread of bounced rays and
+    contribution culling (states whose whole subtree cannot move an accumulator) on scenes nobody tuned them for. Radiance against the oracle
+    with culling, exact ray counts on an RT_NO_CULL context with the same bits; RT_SOAK_HALL_SEEDS=a:b adds seeds."""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emu")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from dump_seed import build_wide
+    hs, os_, lights, meshes, r = build_wide(seed, rt, mirrors=True)
+    ctx.upload_scene(hs)
+    gc, oc = rt.default_camera(1.0, zoom=0.0, z=-10.0), O.default_camera(1.0, zoom=0.0, z=-10.0)
+    gp = rt.make_params(24, 24, spp=1, max_depth=50, jitter=1, shadow_mode=0, seed=seed)
+    op = O.make_params(24, 24, spp=1, max_depth=50, jitter=1, shadow_mode=0, seed=seed)
+    rgb, prim, st = ctx.render(gc, gp)
+    orgb, oprim, ost, _ = os_.render(oc, op, threads=8)
+    huge = np.abs(np.nan_to_num(orgb, nan=0.0, posinf=0.0, neginf=0.0)) >= 5.0e7
+    fin = (np.isfinite(orgb) | np.isnan(orgb)) & ~huge & ~np.isinf(rgb)
+    radiance_check(np.where(fin, rgb, 0.0), np.where(fin, orgb, 0.0), f"hall {seed}")
+    monkeypatch.setenv("RT_NO_CULL", "1")
+    c2 = rt.Context(0)
+    try:
+        c2.upload_scene(hs)
+        rgb2, prim2, st2 = c2.render(gc, gp)
+    finally:
+        c2.close()
+    monkeypatch.delenv("RT_NO_CULL")
+    assert np.array_equal(bits(rgb2), bits(rgb)) and np.array_equal(prim2, prim), f"hall {seed}: culling changed the frame"
+    assert (st2.rays_primary, st2.rays_secondary, st2.rays_shadow) == (ost.rays_primary, ost.rays_secondary, ost.rays_shadow)
+    assert st.rays_secondary <= st2.rays_secondary and st.rays_shadow + st.rays_shadow_culled <= st2.rays_shadow
+
+
 @pytest.mark.parametrize("name", ["mesh_gorilla", "final", "soup:20000"])
 def test_rays_with_nan_and_infinite_components(rt, ctx, name):
     """Rays no camera makes but a bounce off a degenerate triangle's normal does (Mesh.cpp:130 normalises a zero vector), and the seams

@@ -59,7 +59,7 @@ def build(seed, rt):
     return hs, os_, lights, meshes, r
 
 
-def build_wide(seed, rt):
+def build_wide(seed, rt, mirrors=False):
     """A second family of random scenes for the soak runs: triangle soups of a few thousand small triangles with a few huge ones mixed in,
     tree depths 2..22, up to 40 spheres (many-object top levels: batched top-level rounds, sub-trees over objects, the flat pass), one to four
     lights of any size, glass / mirror / checker / diffuse materials at random."""
@@ -110,6 +110,8 @@ def build_wide(seed, rt):
             m.ks[:] = g.uniform(0.1, 1.0, 3).tolist()
             m.shininess = float(g.uniform(1.0, 40.0))
             m.type = int(g.integers(0, 4))
+            if mirrors:                                   # no glass (two children per hit: the reference's recursion doubles per bounce), many mirrors
+                m.type = int(g.choice([0, 2, 2, 2, 3]))
             m.ior = float(g.uniform(1.05, 1.8))
             m.transparency = float(g.uniform(0.1, 0.9)) if m.type == 1 else 0.0
             m.reflectivity = float(g.uniform(0.2, 0.9)) if m.type == 2 else 0.0
