@@ -18,7 +18,7 @@ def emulator(tmp_path_factory):
     if not shutil.which("g++"):
         pytest.skip("no g++")
     exe = str(tmp_path_factory.mktemp("emu") / "shadow_emu")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-ffp-contract=off", "-DRT_HOST_EMU", "-I" + os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-static-libasan", "-ffp-contract=off", "-DRT_HOST_EMU", "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(ROOT, "ray-tracing_amd", "csrc"), "-I" + os.path.join(ROOT, "tools", "emu"), "-Wno-attributes", "-o", exe,
            os.path.join(ROOT, "tools", "emu", "shadow_emu.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
@@ -28,7 +28,7 @@ def emulator(tmp_path_factory):
 
 def test_walks_stay_inside_their_buffers_and_agree_with_the_exact_walk(emulator):
     mode = 0            # the kernel variant the library picks for the scene (k_shadow<2>: fat leaves with sub-trees)
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")      # (statically linked runtime; a preloaded library in the environment must not stop it)
     r = subprocess.run([emulator, FIXTURE, str(mode), "2", "2"], capture_output=True, text=True, timeout=900, env=env)
     if r.returncode == 3:
         pytest.skip("the fixture predates a change of the DScene layout: " + r.stderr.strip()[-200:])
