@@ -556,6 +556,10 @@ int run_wavefront(rt_ctx* c, const Source& src, const WaveBufs& w, long long* ac
                 if ((size_t)std::max<unsigned long long>(blocks, blocks_now) * ovf_cap * RT_BLOCK * sizeof(int) > w.ovf_bytes)
                     return fail(c, RT_ERR_LIMIT, "spill buffer of the shadow walk too small (%d entries per lane)", ovf_cap);
                 int top_min = c->sc.n_top_items >= 24 ? 32 : 1;       /* see k_shadow; measured on the default scene: 1, 8, 16, 32, 48, 60 -> 2365, 2205, 2065, 1828, 1839, 2111 ms */
+                /* a handful of objects around a mesh with fat leaves (k_shadow<2> anyway): rounds of eight lanes (1 / 4 / 8 / 16 / 32: mirror chamber 99.3 /
+                 * 96.7 / 94.9 / 95.1 / 97.8 ms, cow 20.1 / 19.8 / 19.7 / 19.6 / 20.2, gorilla 31.8 / 32.0 / 31.9 / 32.2 / 33.8). Not for scenes without
+                 * sub-trees: a top_min above 1 would take them off the plain kernel (C5) */
+                if (top_min == 1 && c->sc.has_sub) top_min = 8;
                 if (c->sc.has_topsub) top_min = 1;                     /* (with sub-trees over the objects a top-level round is short: 32 / 16 / 8 / 1 -> 94.7 / 93.1 / 92.6 / 91.9 ms on the default scene at 4 spp) */
                 if (const char* e = getenv("RT_TOP_MIN")) top_min = std::max(1, atoi(e));
                 const bool flat_top = c->sc.quant_ok && c->sc.has_topsub && c->sc.n_flat > 0 && w.smask && !front;     /* (its per-ray leaf masks come from k_shadow_setup) */      /* k_shadow<5>: the variant of mode 3 with the flat top-level pass (forced onto the scenes of mode 2 it loses: chamber 122 -> 137 ms, gorilla 42.3 -> 45.2, cow 29.1 -> 31.8 -- they pay for mode 3's plane filter and object sub-trees, and have two to four top-level leaves) */
