@@ -59,7 +59,7 @@ def build(seed, rt):
     return hs, os_, lights, meshes, r
 
 
-def build_wide(seed, rt, mirrors=False):
+def build_wide(seed, rt, mirrors=False, plain=False):
     """A second family of random scenes for the soak runs: triangle soups of a few thousand small triangles with a few huge ones mixed in,
     tree depths 2..22, up to 40 spheres (many-object top levels: batched top-level rounds, sub-trees over objects, the flat pass), one to four
     lights of any size, glass / mirror / checker / diffuse materials at random."""
@@ -72,7 +72,7 @@ def build_wide(seed, rt, mirrors=False):
         size = float(10.0 ** r.uniform(-2.0, -0.3)) * ext
         c = r.uniform(-ext, ext, (nt, 3))
         e1, e2 = r.uniform(-size, size, (nt, 3)), r.uniform(-size, size, (nt, 3))
-        big = r.random(nt) < 0.01
+        big = r.random(nt) < (0.0 if plain else 0.01)          # plain: no huge triangles and a deep tree -> hardly a fat leaf: the plain 4-wide kernel (k_shadow<1>, the one C5 runs)
         e1[big] *= 20.0
         e2[big] *= 20.0
         centre = r.uniform(-2, 2, 3)
@@ -88,6 +88,9 @@ def build_wide(seed, rt, mirrors=False):
     wall = np.array([[-9, -5, -8], [9, -5, -8], [9, 7, -8], [-9, 7, -8]], np.float32)
     floor = np.array([[-9, -5, 7], [9, -5, 7], [9, -5, -8], [-9, -5, -8]], np.float32)
     mesh_depth, top_depth = int(r.integers(2, 23)), int(r.integers(1, 7))
+    if plain:
+        mesh_depth = 24
+        spheres = spheres[:3]
     lights = [(r.uniform(-4, 6, 3).astype(np.float32).tolist(), float(10.0 ** r.uniform(-1.5, 0.8))) for _ in range(int(r.integers(1, 5)))]
     tg = np.random.default_rng(seed + 12345)                   # every third seed: image textures and normal maps (Material.h:86-126) on random materials
     textured = seed % 3 == 0
