@@ -78,7 +78,7 @@ def build_wide(seed, rt, mirrors=False, plain=False):
         centre = r.uniform(-2, 2, 3)
         v = np.stack([c, c + e1, c + e2], axis=1).reshape(-1, 3) + centre
         t = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
-        if r.random() < 0.5:                           # shared vertices: a random re-indexing of a tenth of the corners
+        if r.random() < 0.5 and not plain:             # shared vertices: a random re-indexing of a tenth of the corners
             m = r.random(3 * nt) < 0.1
             t = t.reshape(-1)
             t[m] = r.integers(0, 3 * nt, int(m.sum()))
